@@ -1,0 +1,316 @@
+// 3x3 convolution, NHWC, exact f32 on the matrix cores (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Replaces the F.conv2d calls of [UPSTREAM] ldm/modules/diffusionmodules/model.py:
+//   ResnetBlock.conv1/conv2, Encoder/Decoder conv_in/conv_out      -> MODE 0 (stride 1, pad 1)
+//   Downsample (F.pad(x,(0,1,0,1)) + conv stride 2 pad 0)            -> MODE 1
+//   Upsample (F.interpolate(scale 2, nearest) + conv stride 1 pad 1) -> MODE 2 (no 4x intermediate)
+//   data-gradient of MODE 1 (stride-2 transposed conv)               -> MODE 3
+// reached from src/modules/autoencodermodules/feat_encoder.py:4, feat_decoder.py:4 of the reference.
+// The data-gradient of MODE 0 is MODE 0 itself on weights packed with flipped taps and swapped
+// channel roles (odvae_conv3x3_pack_f32 makes both packs).
+//
+// Implicit GEMM: M = output pixels (block tile = 8x16 patch = 128 px), N = Cout, K = 9 taps x Cin.
+// Per chunk of KC input channels the block stages the input halo patch once ([halo px][KC] in LDS,
+// reused by all 9 taps) and streams the 9 per-tap weight slices [KC/4][BN][4] through a 2-deep LDS
+// ring (loads for tap t+1 are issued into registers before tap t's MFMAs, written after them).
+// A and B fragments are ds_read_b128: four k-steps per read, k order (8g + 4*half + j) on both.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;  // output pixels per block tile (TH*TW = 128)
+
+struct ConvParams {
+  const float* x;         // [N][Hi][Wi][Cin]
+  const float* wpk;       // [9][CinP/4][CoutP][4]
+  const float* bias;      // [Cout] or null
+  const float* residual;  // [N][Ho][Wo][Cout] or null
+  float* y;               // [N][Ho][Wo][Cout]
+  int N, Hi, Wi, Cin, Ho, Wo, Cout, CinP, CoutP;
+  int tiles_x, tiles_y;
+};
+
+template <int MODE> struct Halo;
+template <> struct Halo<0> { static constexpr int H = TH + 2, W = TW + 2; };
+template <> struct Halo<1> { static constexpr int H = 2 * TH + 1, W = 2 * TW + 1; };
+template <> struct Halo<2> { static constexpr int H = TH / 2 + 2, W = TW / 2 + 2; };
+template <> struct Halo<3> { static constexpr int H = TH / 2 + 1, W = TW / 2 + 1; };
+
+// halo pixel index for output pixel (r,c) of the tile and tap (kh,kw); ok=false -> operand is zero
+template <int MODE>
+__device__ __forceinline__ int halo_index(int r, int c, int kh, int kw, bool& ok) {
+  ok = true;
+  if (MODE == 0) return (r + kh) * Halo<0>::W + (c + kw);
+  if (MODE == 1) return (2 * r + kh) * Halo<1>::W + (2 * c + kw);
+  if (MODE == 2) return ((r + kh + 1) >> 1) * Halo<2>::W + ((c + kw + 1) >> 1);
+  ok = (((r + kh) | (c + kw)) & 1) == 0;
+  return ((r + kh) >> 1) * Halo<3>::W + ((c + kw) >> 1);
+}
+
+// top-left input pixel of the halo patch of the tile whose first output pixel is (oy0, ox0)
+template <int MODE>
+__device__ __forceinline__ void halo_origin(int oy0, int ox0, int& iy0, int& ix0) {
+  if (MODE == 0) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
+  else if (MODE == 1) { iy0 = 2 * oy0; ix0 = 2 * ox0; }
+  else { iy0 = oy0 / 2 - 1; ix0 = ox0 / 2 - 1; }
+}
+
+// WMT x WNT MFMA tiles per wave, WAVES_M x WAVES_N waves (4 waves; WAVES_M*WMT = 4 M-tiles of 32 px)
+template <int MODE, int KC, int WMT, int WNT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * WMT == 4, "tile layout");
+  constexpr int BN = WAVES_N * WNT * 32;
+  constexpr int HS = KC + 4;                          // halo row stride (floats)
+  constexpr int HPIX = Halo<MODE>::H * Halo<MODE>::W;
+  constexpr int QC = KC / 4;                          // channel quads per chunk
+  constexpr int HALO_F4 = HPIX * QC;                  // float4 per halo stage
+  constexpr int HALO_IT = (HALO_F4 + 255) / 256;
+  constexpr int W_F4 = QC * BN;                       // float4 per tap slice
+  constexpr int W_IT = (W_F4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[HPIX * HS + 2 * W_F4 * 4];
+  float* Hs = smem;
+  float* Ws = smem + HPIX * HS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, h = lane >> 5;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN;
+  int iy0, ix0;
+  halo_origin<MODE>(oy0, ox0, iy0, ix0);
+  const float* xn = p.x + (int64_t)n * p.Hi * p.Wi * p.Cin;
+  const bool vec = (p.Cin & 3) == 0;
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int a = 0; a < WMT; ++a)
+#pragma unroll
+    for (int b = 0; b < WNT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 hreg[HALO_IT], wreg[W_IT];
+
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < HALO_F4) {
+        const int hp = f / QC, q = f % QC;
+        const int iy = iy0 + hp / Halo<MODE>::W, ix = ix0 + hp % Halo<MODE>::W;
+        const int c = c0 + 4 * q;
+        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin) {
+          const float* src = xn + ((int64_t)iy * p.Wi + ix) * p.Cin + c;
+          if (vec) v = *reinterpret_cast<const float4*>(src);
+          else {
+            v.x = src[0];
+            if (c + 1 < p.Cin) v.y = src[1];
+            if (c + 2 < p.Cin) v.z = src[2];
+            if (c + 3 < p.Cin) v.w = src[3];
+          }
+        }
+      }
+      hreg[i] = v;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      if (f < HALO_F4) *reinterpret_cast<float4*>(Hs + (f / QC) * HS + 4 * (f % QC)) = hreg[i];
+    }
+  };
+  auto load_w = [&](int c0, int tap) {
+    const float* src = p.wpk + ((int64_t)tap * (p.CinP / 4) + c0 / 4) * p.CoutP * 4;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int f = tid + 256 * i;
+      if (f < W_F4) {
+        const int q = f / BN, nn = f % BN;
+        wreg[i] = *reinterpret_cast<const float4*>(src + ((int64_t)q * p.CoutP + n0 + nn) * 4);
+      }
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int f = tid + 256 * i;
+      if (f < W_F4) *reinterpret_cast<float4*>(Ws + (buf * W_F4 + f) * 4) = wreg[i];
+    }
+  };
+
+  const int nchunks = p.CinP / KC;
+  load_halo(0);
+  load_w(0, 0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    store_halo();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      store_w(tap & 1);
+      __syncthreads();
+      // prefetch the next weight slice (and, near the end of the chunk, the next halo)
+      if (tap < 8) load_w(ch * KC, tap + 1);
+      else if (ch + 1 < nchunks) load_w((ch + 1) * KC, 0);
+      if (tap == 7 && ch + 1 < nchunks) load_halo((ch + 1) * KC);
+
+      const int kh = tap / 3, kw = tap % 3;
+      int aoff[WMT]; bool aok[WMT];
+#pragma unroll
+      for (int mt = 0; mt < WMT; ++mt) {
+        const int pm = (wm * WMT + mt) * 32 + li;
+        aoff[mt] = halo_index<MODE>(pm / TW, pm % TW, kh, kw, aok[mt]) * HS + 4 * h;
+      }
+      const float* Wb = Ws + (tap & 1) * W_F4 * 4;
+#pragma unroll
+      for (int g = 0; g < KC / 8; ++g) {
+        float4 a[WMT], b[WNT];
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt) {
+          a[mt] = *reinterpret_cast<const float4*>(Hs + aoff[mt] + g * 8);
+          if (MODE == 3 && !aok[mt]) a[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < WNT; ++nt)
+          b[nt] = *reinterpret_cast<const float4*>(Wb + ((g * 2 + h) * BN + (wn * WNT + nt) * 32 + li) * 4);
+#pragma unroll
+        for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WNT; ++nt) {
+            acc[mt][nt] = mfma32(a[mt].x, b[nt].x, acc[mt][nt]);
+            acc[mt][nt] = mfma32(a[mt].y, b[nt].y, acc[mt][nt]);
+            acc[mt][nt] = mfma32(a[mt].z, b[nt].z, acc[mt][nt]);
+            acc[mt][nt] = mfma32(a[mt].w, b[nt].w, acc[mt][nt]);
+          }
+      }
+    }
+    __syncthreads();  // every wave is done with this chunk's halo before it is overwritten
+  }
+
+  // epilogue: lane = output channel, registers = pixels
+  float* yn = p.y + (int64_t)n * p.Ho * p.Wo * p.Cout;
+  const float* rn = p.residual ? p.residual + (int64_t)n * p.Ho * p.Wo * p.Cout : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt) {
+    const int co = n0 + (wn * WNT + nt) * 32 + li;
+    if (co >= p.Cout) continue;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
+        const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
+        if (oy < p.Ho && ox < p.Wo) {
+          const int64_t o = ((int64_t)oy * p.Wo + ox) * p.Cout + co;
+          float v = acc[mt][nt][r] + bv;
+          if (rn) v += rn[o];
+          yn[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// OIHW -> fwd pack [t][CinP/4][CoutP][4] and dgrad pack [t'][CoutP_d/4][CinP_d][4] (flipped taps)
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                    float* __restrict__ fwd, int CinP_f, int CoutP_f,
+                                    float* __restrict__ dgr, int CoutP_d, int CinP_d) {
+  // fwd pack: reduction channels = Cin (padded CinP_f), output channels = Cout (padded CoutP_f)
+  const int64_t nf = fwd ? (int64_t)9 * CinP_f * CoutP_f : 0;
+  // dgrad pack: reduction channels = Cout (padded CoutP_d), output channels = Cin (padded CinP_d)
+  const int64_t nd = dgr ? (int64_t)9 * CoutP_d * CinP_d : 0;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx < nf) {
+      int64_t r = idx;
+      const int j = r & 3; r >>= 2;
+      const int co = (int)(r % CoutP_f); r /= CoutP_f;
+      const int q = (int)(r % (CinP_f / 4)); const int tap = (int)(r / (CinP_f / 4));
+      const int ci = 4 * q + j;
+      fwd[idx] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
+    } else {
+      int64_t r = idx - nf;
+      const int j = r & 3; r >>= 2;
+      const int ci = (int)(r % CinP_d); r /= CinP_d;
+      const int q = (int)(r % (CoutP_d / 4)); const int tap = (int)(r / (CoutP_d / 4));
+      const int co = 4 * q + j;
+      dgr[idx - nf] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * 9 + (8 - tap)] : 0.f;
+    }
+  }
+}
+
+constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" {
+
+// padded reduction / output channel counts of a weight pack (reduce = channels summed over)
+int odvae_conv3x3_pack_reduce_pad(int c_reduce) { return round_up(c_reduce, 16); }
+int odvae_conv3x3_pack_out_pad(int c_out) { return c_out <= 32 ? 32 : round_up(c_out, 128); }
+
+// floats in a pack whose reduction axis has c_reduce channels and output axis c_out channels
+size_t odvae_conv3x3_pack_floats(int c_reduce, int c_out) {
+  return (size_t)9 * odvae_conv3x3_pack_reduce_pad(c_reduce) * odvae_conv3x3_pack_out_pad(c_out);
+}
+
+// w: OIHW [Cout][Cin][3][3].  fwd_pack (may be null) has odvae_conv3x3_pack_floats(Cin, Cout) floats,
+// dgrad_pack (may be null) has odvae_conv3x3_pack_floats(Cout, Cin) floats.
+int odvae_conv3x3_pack_f32(const float* w, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream) {
+  ODVAE_CHECK_ARG(w && Cout > 0 && Cin > 0, "conv3x3_pack: bad arguments");
+  const int CinP_f = odvae_conv3x3_pack_reduce_pad(Cin), CoutP_f = odvae_conv3x3_pack_out_pad(Cout);
+  const int CoutP_d = odvae_conv3x3_pack_reduce_pad(Cout), CinP_d = odvae_conv3x3_pack_out_pad(Cin);
+  const int64_t total = (fwd_pack ? (int64_t)9 * CinP_f * CoutP_f : 0) + (dgrad_pack ? (int64_t)9 * CoutP_d * CinP_d : 0);
+  if (total == 0) return ODVAE_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 2048);
+  hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d);
+  ODVAE_LAUNCH_CHECK("conv3x3_pack");
+  return ODVAE_OK;
+}
+
+// y = conv3x3(x) (+bias) (+residual).  mode: 0 stride 1 pad 1 | 1 pad(0,1,0,1)+stride 2 |
+// 2 nearest-2x-upsample then stride 1 pad 1 | 3 transposed stride 2 (data gradient of mode 1).
+// wpk: pack with reduction axis Cin and output axis Cout (for data gradients pass the dgrad pack,
+// Cin = channels of x (= dy), Cout = channels of y (= dx)).
+int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
+                      const float* wpk, int Cout, const float* bias, const float* residual,
+                      float* y, int Ho, int Wo, void* stream) {
+  ODVAE_CHECK_ARG(x && wpk && y, "conv3x3: null operand");
+  ODVAE_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv3x3: empty shape");
+  ODVAE_CHECK_ARG(mode >= 0 && mode <= 3, "conv3x3: mode %d", mode);
+  if (mode == 0) ODVAE_CHECK_ARG(Ho == Hi && Wo == Wi, "conv3x3 mode 0: Ho,Wo must equal Hi,Wi");
+  if (mode == 1) ODVAE_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv3x3 mode 1: need even Hi,Wi and Ho=Hi/2");
+  if (mode == 2 || mode == 3) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3 mode %d: need Ho=2*Hi", mode);
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wpk & 15) == 0, "conv3x3: x/wpk must be 16-byte aligned");
+
+  ConvParams p;
+  p.x = x; p.wpk = wpk; p.bias = bias; p.residual = residual; p.y = y;
+  p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+  p.CinP = odvae_conv3x3_pack_reduce_pad(Cin); p.CoutP = odvae_conv3x3_pack_out_pad(Cout);
+  p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, TH);
+  const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
+  ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3: too many tiles");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool narrow = Cout <= 32;
+  dim3 block(256);
+#define ODVAE_CONV_LAUNCH(MODE, KC)                                                                      \
+  if (narrow) hipLaunchKernelGGL((conv3x3_kernel<MODE, KC, 1, 1, 4, 1>), dim3((unsigned)sp, p.CoutP / 32), block, 0, st, p); \
+  else hipLaunchKernelGGL((conv3x3_kernel<MODE, KC, 2, 2, 2, 2>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p)
+  switch (mode) {
+    case 0: ODVAE_CONV_LAUNCH(0, 16); break;
+    case 1: ODVAE_CONV_LAUNCH(1, 8); break;
+    case 2: ODVAE_CONV_LAUNCH(2, 16); break;
+    default: ODVAE_CONV_LAUNCH(3, 16); break;
+  }
+#undef ODVAE_CONV_LAUNCH
+  ODVAE_LAUNCH_CHECK("conv3x3");
+  return ODVAE_OK;
+}
+
+}  // extern "C"

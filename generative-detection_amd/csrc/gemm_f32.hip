@@ -1,0 +1,263 @@
+// Exact-f32 matrix-core GEMM for gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Serves the "dense contraction" rows of the hot path: 1x1 convolutions
+// (nin_shortcut, attention q/k/v/proj_out, quant convs: [UPSTREAM] ldm/modules/diffusionmodules/model.py
+// ResnetBlock/AttnBlock; src/models/autoencoder.py:88-90) in NHWC, their dgrad/wgrad, and the
+// batched products of single-head attention (AttnBlock.forward: bmm(q,k), bmm(v,w_)).
+//
+// C[b] = alpha * op(A[b]) * op(B[b]) (+ bias[col]) (+ residual[b]),  row-major everywhere.
+//   transA = 0: A stored [M][K] (k contiguous)   transA = 1: A stored [K][M]
+//   transB = 0: B stored [K][N] (n contiguous)   transB = 1: B stored [N][K]
+//
+// Block = 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 2x2 MFMA tiles,
+// BK = 32.  Operand tiles go through LDS; k-contiguous tiles are kept [row][k] (+4 pad, so the
+// 16 rows of a ds_read_b128 lane group land on 16 disjoint 4-bank slots) and read as b128 =
+// four k-steps per read; row-contiguous tiles are kept [k][row] and read as b32 (lanes =
+// consecutive rows, conflict-free).  Both reads use the same k order inside a group of 8:
+// step j of lane half h is k = 8g + 4h + j, so A and B always agree.
+// Split-K (grid.y) covers the long-K/small-MN products (wgrad: K = B*H*W).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_KC = BK + 4;    // [row][k] tile row stride (floats)
+constexpr int LDS_RC = BM + 4;    // [k][row] tile row stride (floats)
+constexpr int TILE_FLOATS = BM * LDS_KC;  // 4608 >= BK*LDS_RC = 4224
+
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  const float* bias; const float* residual;
+  float* partial;      // split-K slabs [split][batch][M][N] or nullptr
+  int M, N, K;
+  int lda, ldb, ldc;
+  int64_t sA, sB, sC;
+  float alpha;
+  int splits, k_per_split;
+  int tiles_m;
+};
+
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int row0, int nrows,
+                                          int k0, int kend, float4 (&r)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int row = row0 + (f >> 3), k = k0 + 4 * (f & 7);
+      if (row < nrows && k < kend) v = *reinterpret_cast<const float4*>(G + (int64_t)row * ld + k);
+    } else {
+      const int k = k0 + (f >> 5), row = row0 + 4 * (f & 31);
+      if (k < kend && row < nrows) v = *reinterpret_cast<const float4*>(G + (int64_t)k * ld + row);
+    }
+    r[i] = v;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* S, const float4 (&r)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + 256 * i;
+    if (KC) *reinterpret_cast<float4*>(S + (f >> 3) * LDS_KC + 4 * (f & 7)) = r[i];
+    else    *reinterpret_cast<float4*>(S + (f >> 5) * LDS_RC + 4 * (f & 31)) = r[i];
+  }
+}
+
+// fragment for one 32-row MFMA tile, k-group g (8 k values), this lane's 4 steps
+template <bool KC>
+__device__ __forceinline__ void read_frag(const float* S, int row, int g, int h, float (&a)[4]) {
+  if (KC) {
+    const float4 v = *reinterpret_cast<const float4*>(S + row * LDS_KC + g * 8 + 4 * h);
+    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = S[(g * 8 + 4 * h + j) * LDS_RC + row];
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+  float* As = smem;
+  float* Bs = smem + TILE_FLOATS;
+
+  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  const int split = blockIdx.y, batch = blockIdx.z;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  const float* A = p.A + batch * p.sA;
+  const float* B = p.B + batch * p.sB;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  if (kbeg < kend) {
+    load_tile<A_KC>(A, p.lda, m0, p.M, kbeg, kend, ra);
+    load_tile<B_KC>(B, p.ldb, n0, p.N, kbeg, kend, rb);
+    store_tile<A_KC>(As, ra);
+    store_tile<B_KC>(Bs, rb);
+  }
+  __syncthreads();
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool has_next = (k0 + BK) < kend;
+    if (has_next) {
+      load_tile<A_KC>(A, p.lda, m0, p.M, k0 + BK, kend, ra);
+      load_tile<B_KC>(B, p.ldb, n0, p.N, k0 + BK, kend, rb);
+    }
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float a[2][4], b[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        read_frag<A_KC>(As, wm * 64 + t * 32 + li, g, h, a[t]);
+        read_frag<B_KC>(Bs, wn * 64 + t * 32 + li, g, h, b[t]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(a[mt][j], b[nt][j], acc[mt][nt]);
+    }
+    __syncthreads();
+    if (has_next) {
+      store_tile<A_KC>(As, ra);
+      store_tile<B_KC>(Bs, rb);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: lane owns column (n0 + wn*64 + nt*32 + li); rows come from the register index
+  const bool to_partial = p.partial != nullptr;
+  float* C = to_partial ? p.partial + ((int64_t)split * gridDim.z + batch) * (int64_t)p.M * p.N
+                        : p.C + batch * p.sC;
+  const int ldc = to_partial ? p.N : p.ldc;
+  const float* R = (!to_partial && p.residual) ? p.residual + batch * p.sC : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wn * 64 + nt * 32 + li;
+      if (col >= p.N) continue;
+      const float bv = (!to_partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mt * 32 + acc_row(r, lane);
+        if (row < p.M) {
+          float v = acc[mt][nt][r];
+          if (!to_partial) {
+            v = v * p.alpha + bv;
+            if (R) v += R[(int64_t)row * ldc + col];
+          }
+          C[(int64_t)row * ldc + col] = v;
+        }
+      }
+    }
+}
+
+// sums the split-K slabs, then alpha / bias / residual
+__global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
+  const int64_t mn = (int64_t)p.M * p.N;
+  const int64_t total = mn * batches;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int batch = (int)(idx / mn);
+    const int64_t rem = idx - (int64_t)batch * mn;
+    const int row = (int)(rem / p.N), col = (int)(rem - (int64_t)row * p.N);
+    float s = 0.f;
+    for (int sp = 0; sp < p.splits; ++sp) s += p.partial[((int64_t)sp * batches + batch) * mn + rem];
+    s *= p.alpha;
+    if (p.bias) s += p.bias[col];
+    const int64_t o = batch * p.sC + (int64_t)row * p.ldc + col;
+    if (p.residual) s += p.residual[o];
+    p.C[o] = s;
+  }
+}
+
+int choose_splits(int M, int N, int K, int batch) {
+  const int64_t tiles = (int64_t)ceil_div(M, BM) * ceil_div(N, BN) * batch;
+  if (tiles >= 512 || K <= 1024) return 1;
+  int64_t s = 1024 / tiles;
+  const int64_t max_by_k = K / 512;  // at least 16 k-tiles per split
+  if (s > max_by_k) s = max_by_k;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of split-K scratch odvae_gemm_f32 needs for this shape (0 when it runs unsplit)
+size_t odvae_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
+  const int s = choose_splits(M, N, K, batch);
+  return s > 1 ? (size_t)s * batch * M * N * sizeof(float) : 0;
+}
+
+int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                   const float* A, int lda, int64_t strideA,
+                   const float* B, int ldb, int64_t strideB,
+                   float* C, int ldc, int64_t strideC,
+                   const float* bias, const float* residual, int batch,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_f32: empty shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  ODVAE_CHECK_ARG(A && B && C, "gemm_f32: null operand");
+  ODVAE_CHECK_ARG(batch <= 65535, "gemm_f32: batch %d > 65535", batch);
+  // float4 staging: the contiguous axis of each operand must be a multiple of 4 and 16-byte aligned
+  ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0,
+                  "gemm_f32: lda/ldb/strides must be multiples of 4 floats");
+  ODVAE_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_f32: A/B must be 16-byte aligned");
+  ODVAE_CHECK_ARG(K % 4 == 0, "gemm_f32: K=%d must be a multiple of 4", K);
+  if (transA) ODVAE_CHECK_ARG(M % 4 == 0, "gemm_f32: transA needs M %% 4 == 0 (M=%d)", M);
+  if (!transB) ODVAE_CHECK_ARG(N % 4 == 0, "gemm_f32: transB=0 needs N %% 4 == 0 (N=%d)", N);
+
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
+  p.splits = choose_splits(M, N, K, batch);
+  p.k_per_split = ceil_div(ceil_div(K, p.splits), BK) * BK;
+  p.tiles_m = ceil_div(M, BM);
+  if (p.splits > 1) {
+    const size_t need = (size_t)p.splits * batch * M * N * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+      odvae_set_error("gemm_f32: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
+      return ODVAE_ERR_WORKSPACE;
+    }
+    p.partial = static_cast<float*>(workspace);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(p.tiles_m * ceil_div(N, BN), p.splits, batch), block(256);
+  const bool a_kc = !transA, b_kc = transB != 0;
+  if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, p);
+  else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, p);
+  else if (!a_kc && b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, p);
+  else                     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, st, p);
+  ODVAE_LAUNCH_CHECK("gemm_f32");
+  if (p.splits > 1) {
+    const int64_t total = (int64_t)M * N * batch;
+    const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, batch);
+    ODVAE_LAUNCH_CHECK("gemm_f32 split-K reduce");
+  }
+  return ODVAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// GroupNorm (+ optional swish) forward/backward, NHWC f32, gfx950.  HBM-bound.
+//
+// [UPSTREAM] ldm/modules/diffusionmodules/model.py: Normalize = GroupNorm(32, C, eps=1e-6, affine=True),
+// nonlinearity(x) = x*sigmoid(x); 67 sites in Encoder/Decoder (ResnetBlock.norm1/norm2, AttnBlock.norm,
+// norm_out), reached from src/modules/autoencodermodules/feat_encoder.py:4 / feat_decoder.py:4.
+//
+// x is [N][HW][C].  Statistics: each block reduces a run of pixels of one sample with float4 loads
+// (a wavefront reads 1 KiB of contiguous channels), per-thread f32 sums over <= a few hundred values,
+// LDS tree to per-channel sums, then per-group partials; a finalize kernel combines the partials in
+// f64 (fixed order => deterministic) into mean / rstd.  Apply is a pure streaming float4 pass.
+// Backward recomputes xhat and the swish derivative from x (nothing but x, mean, rstd is saved).
+#include "common.h"
+
+namespace {
+
+struct GnShape {
+  int N, HW, C, G, cpg;      // cpg = C / G
+  int quads;                 // C / 4
+  int pix_per_pass;          // 256 / quads
+  int chunks, pix_per_chunk;
+};
+
+__device__ __forceinline__ float swish_f(float u) { return u / (1.f + __expf(-u)); }
+
+// ---- forward statistics -------------------------------------------------------------------------
+// partial: [N][chunks][G][2]  (sum, sum of squares)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, GnShape s, float* __restrict__ partial) {
+  __shared__ float red[2][256 * 4];  // [stat][psub][C] flattened: psub*C + c  (pix_per_pass*C = 1024)
+  const int tid = threadIdx.x;
+  const int q = tid % s.quads, psub = tid / s.quads;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int p_beg = chunk * s.pix_per_chunk;
+  const int p_end = min(s.HW, p_beg + s.pix_per_chunk);
+  const float* xn = x + (int64_t)n * s.HW * s.C + 4 * q;
+  float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
+  if (psub < s.pix_per_pass) {
+    for (int px = p_beg + psub; px < p_end; px += s.pix_per_pass) {
+      const float4 v = *reinterpret_cast<const float4*>(xn + (int64_t)px * s.C);
+      sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+      sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    }
+    *reinterpret_cast<float4*>(&red[0][psub * s.C + 4 * q]) = sm;
+    *reinterpret_cast<float4*>(&red[1][psub * s.C + 4 * q]) = sq;
+  }
+  __syncthreads();
+  // per-channel totals (threads stride over channels), written back to row 0
+  for (int c = tid; c < s.C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int ps = 0; ps < s.pix_per_pass; ++ps) { a += red[0][ps * s.C + c]; b += red[1][ps * s.C + c]; }
+    red[0][c] = a; red[1][c] = b;   // row 0 only read by its own writer in this loop
+  }
+  __syncthreads();
+  if (tid < s.G) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < s.cpg; ++j) { a += red[0][tid * s.cpg + j]; b += red[1][tid * s.cpg + j]; }
+    float* o = partial + (((int64_t)n * s.chunks + chunk) * s.G + tid) * 2;
+    o[0] = a; o[1] = b;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, GnShape s, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= s.N * s.G) return;
+  const int n = idx / s.G, g = idx % s.G;
+  double a = 0.0, b = 0.0;
+  for (int ch = 0; ch < s.chunks; ++ch) {
+    const float* o = partial + (((int64_t)n * s.chunks + ch) * s.G + g) * 2;
+    a += (double)o[0]; b += (double)o[1];
+  }
+  const double m = (double)s.HW * s.cpg;
+  const double mu = a / m;
+  double var = b / m - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[idx] = (float)mu;
+  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---- forward apply -------------------------------------------------------------------------------
+template <bool SWISH>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, GnShape s,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       float* __restrict__ y) {
+  const int64_t per_n = (int64_t)s.HW * s.quads;
+  const int64_t total = per_n * s.N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / per_n);
+    const int q = (int)(idx % s.quads);
+    const int c = 4 * q;
+    const float4 v = *reinterpret_cast<const float4*>(x + idx * 4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    float in[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = (c + j) / s.cpg;
+      const float mu = mean[n * s.G + g], rs = rstd[n * s.G + g];
+      const float u = (in[j] - mu) * rs * gg[j] + bb[j];
+      out[j] = SWISH ? swish_f(u) : u;
+    }
+    *reinterpret_cast<float4*>(y + idx * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+// du = dy * d(act)/du with u = xhat*gamma + beta.  Pass 1: per-(n, chunk, c) sums of du*xhat and du.
+template <bool SWISH>
+__device__ __forceinline__ float act_grad(float u) {
+  if (!SWISH) return 1.f;
+  const float sg = 1.f / (1.f + __expf(-u));
+  return sg * (1.f + u * (1.f - sg));
+}
+
+// partial: [N][chunks][2][C]
+template <bool SWISH>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, GnShape s,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[2][256 * 4];
+  const int tid = threadIdx.x;
+  const int q = tid % s.quads, psub = tid / s.quads;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int p_beg = chunk * s.pix_per_chunk;
+  const int p_end = min(s.HW, p_beg + s.pix_per_chunk);
+  const int c = 4 * q;
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (psub < s.pix_per_pass) {
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    float mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int g = (c + j) / s.cpg; mu[j] = mean[n * s.G + g]; rs[j] = rstd[n * s.G + g]; }
+    const int64_t base = (int64_t)n * s.HW * s.C + c;
+    for (int px = p_beg + psub; px < p_end; px += s.pix_per_pass) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + (int64_t)px * s.C);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + base + (int64_t)px * s.C);
+      const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xi[j] - mu[j]) * rs[j];
+        const float du = di[j] * act_grad<SWISH>(xh * gg[j] + bb[j]);
+        a[j] += du * xh; b[j] += du;
+      }
+    }
+    *reinterpret_cast<float4*>(&red[0][psub * s.C + c]) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(&red[1][psub * s.C + c]) = make_float4(b[0], b[1], b[2], b[3]);
+  }
+  __syncthreads();
+  float* o = partial + ((int64_t)n * s.chunks + chunk) * 2 * s.C;
+  for (int cc = tid; cc < s.C; cc += 256) {
+    float sa = 0.f, sb = 0.f;
+    for (int ps = 0; ps < s.pix_per_pass; ++ps) { sa += red[0][ps * s.C + cc]; sb += red[1][ps * s.C + cc]; }
+    o[cc] = sa; o[s.C + cc] = sb;
+  }
+}
+
+// per (n, c): A = sum du*xhat, B = sum du (f64 over chunks).  One block per sample, thread per channel.
+// Writes chan[n][2][C] and the per-group ds1 = sum_c gamma*A, ds2 = sum_c gamma*B into grp[n][G][2].
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, GnShape s, const float* __restrict__ gamma,
+                                       float* __restrict__ chan, float* __restrict__ grp) {
+  extern __shared__ float sh[];  // [2][C]
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
+    double a = 0.0, b = 0.0;
+    for (int ch = 0; ch < s.chunks; ++ch) {
+      const float* o = partial + ((int64_t)n * s.chunks + ch) * 2 * s.C;
+      a += (double)o[c]; b += (double)o[s.C + c];
+    }
+    chan[((int64_t)n * 2 + 0) * s.C + c] = (float)a;
+    chan[((int64_t)n * 2 + 1) * s.C + c] = (float)b;
+    sh[c] = (float)(a * (double)gamma[c]);
+    sh[s.C + c] = (float)(b * (double)gamma[c]);
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < s.G; g += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < s.cpg; ++j) { a += sh[g * s.cpg + j]; b += sh[s.C + g * s.cpg + j]; }
+    grp[((int64_t)n * s.G + g) * 2 + 0] = a;
+    grp[((int64_t)n * s.G + g) * 2 + 1] = b;
+  }
+}
+
+// dgamma[c] = sum_n A[n][c], dbeta[c] = sum_n B[n][c]
+__global__ void gn_bwd_param_kernel(const float* __restrict__ chan, int N, int C,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int n = 0; n < N; ++n) { a += (double)chan[((int64_t)n * 2 + 0) * C + c]; b += (double)chan[((int64_t)n * 2 + 1) * C + c]; }
+  dgamma[c] = (float)a;
+  dbeta[c] = (float)b;
+}
+
+// dx = rstd * (du*gamma - (ds2 + xhat*ds1)/m)
+template <bool SWISH>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, GnShape s,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ grp, float* __restrict__ dx) {
+  const int64_t per_n = (int64_t)s.HW * s.quads;
+  const int64_t total = per_n * s.N;
+  const float inv_m = 1.f / ((float)s.HW * (float)s.cpg);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / per_n);
+    const int q = (int)(idx % s.quads);
+    const int c = 4 * q;
+    const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4);
+    const float4 dv = *reinterpret_cast<const float4*>(dy + idx * 4);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = (c + j) / s.cpg;
+      const float mu = mean[n * s.G + g], rs = rstd[n * s.G + g];
+      const float ds1 = grp[((int64_t)n * s.G + g) * 2 + 0], ds2 = grp[((int64_t)n * s.G + g) * 2 + 1];
+      const float xh = (xi[j] - mu) * rs;
+      const float du = di[j] * act_grad<SWISH>(xh * gg[j] + bb[j]);
+      out[j] = rs * (du * gg[j] - (ds2 + xh * ds1) * inv_m);
+    }
+    *reinterpret_cast<float4*>(dx + idx * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+bool make_shape(int N, int HW, int C, int G, GnShape& s) {
+  if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0 || C % 4 != 0) return false;
+  s.N = N; s.HW = HW; s.C = C; s.G = G; s.cpg = C / G; s.quads = C / 4;
+  if (s.quads > 256 || G > 256) return false;
+  s.pix_per_pass = 256 / s.quads;
+  // aim for >= ~2048 blocks overall, at least 64 pixels per block
+  int chunks = ceil_div(2048, N);
+  const int max_chunks = ceil_div(HW, 64);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  s.pix_per_chunk = ceil_div(HW, chunks);
+  s.chunks = ceil_div(HW, s.pix_per_chunk);
+  return true;
+}
+
+int grid_1d(int64_t work_items) { return (int)std::min<int64_t>(ceil_div64(work_items, 256), 8192); }
+
+}  // namespace
+
+extern "C" {
+
+// scratch for forward (stats partials) and backward (channel partials + chan + grp)
+size_t odvae_groupnorm_workspace_bytes(int N, int HW, int C, int G) {
+  GnShape s;
+  if (!make_shape(N, HW, C, G, s)) return 0;
+  const size_t fwd = (size_t)N * s.chunks * G * 2;
+  const size_t bwd = (size_t)N * s.chunks * 2 * C + (size_t)N * 2 * C + (size_t)N * G * 2;
+  return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+// y = act(GroupNorm(x)); mean/rstd [N][G] are outputs (saved for backward).  swish: 0 = identity, 1 = x*sigmoid(x)
+int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                            float eps, int swish, float* y, float* mean, float* rstd,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  GnShape s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_fwd: unsupported shape N=%d HW=%d C=%d G=%d (need C%%G==0, C%%4==0, C<=1024)", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && gamma && beta && y && mean && rstd, "groupnorm_fwd: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0,
+                  "groupnorm_fwd: operands must be 16-byte aligned");
+  const size_t need = (size_t)N * s.chunks * G * 2 * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    odvae_set_error("groupnorm_fwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return ODVAE_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(s.chunks, N), dim3(256), 0, st, x, s, partial);
+  ODVAE_LAUNCH_CHECK("groupnorm stats");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(N * G, 256)), dim3(256), 0, st, partial, s, eps, mean, rstd);
+  ODVAE_LAUNCH_CHECK("groupnorm finalize");
+  const int blocks = grid_1d((int64_t)N * HW * s.quads);
+  if (swish) hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(blocks), dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  else       hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(blocks), dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  ODVAE_LAUNCH_CHECK("groupnorm apply");
+  return ODVAE_OK;
+}
+
+// dx, dgamma[C], dbeta[C] from dy (gradient w.r.t. the activated output), x and the saved mean/rstd
+int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
+                            const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
+                            float* dx, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  GnShape s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_bwd: unsupported shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta, "groupnorm_bwd: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0, "groupnorm_bwd: operands must be 16-byte aligned");
+  const size_t need = odvae_groupnorm_workspace_bytes(N, HW, C, G);
+  if (!workspace || workspace_bytes < need) {
+    odvae_set_error("groupnorm_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return ODVAE_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  float* chan = partial + (size_t)N * s.chunks * 2 * C;
+  float* grp = chan + (size_t)N * 2 * C;
+  if (swish) hipLaunchKernelGGL((gn_bwd_reduce_kernel<true>), dim3(s.chunks, N), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, partial);
+  else       hipLaunchKernelGGL((gn_bwd_reduce_kernel<false>), dim3(s.chunks, N), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, partial);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd reduce");
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 2 * C * sizeof(float), st, partial, s, gamma, chan, grp);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd finalize");
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd param");
+  const int blocks = grid_1d((int64_t)N * HW * s.quads);
+  if (swish) hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx);
+  else       hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd apply");
+  return ODVAE_OK;
+}
+
+}  // extern "C"

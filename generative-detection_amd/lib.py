@@ -1,0 +1,129 @@
+"""ctypes binding of libodvae_hip.so (include/odvae_hip.h).  The product path has no CPU fallback:
+every op raises if the library is missing or the tensors are not on a HIP device."""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libodvae_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "odvae_hip.h")
+
+_c = ctypes
+_P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/odvae_hip.h one to one (tests/test_abi.py checks that)
+PROTOTYPES = {
+    "odvae_last_error": (_c.c_char_p, []),
+    "odvae_abi_version": (_I, []),
+    "odvae_target_arch": (_c.c_char_p, []),
+    "odvae_gemm_f32_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "odvae_gemm_f32": (_I, [_I, _I, _I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _P, _I, _P, _Z, _P]),
+    "odvae_conv3x3_pack_reduce_pad": (_I, [_I]),
+    "odvae_conv3x3_pack_out_pad": (_I, [_I]),
+    "odvae_conv3x3_pack_floats": (_Z, [_I, _I]),
+    "odvae_conv3x3_pack_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "odvae_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "odvae_groupnorm_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
+    "odvae_groupnorm_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "odvae_softmax_rows_f32": (_I, [_P, _P, _L, _I, _F, _P]),
+    "odvae_softmax_rows_bwd_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "odvae_upsample2x_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "odvae_rescale_minmax_f32": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, _P]),
+    "odvae_gaussian_sample_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "odvae_gaussian_kl_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "odvae_gaussian_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "odvae_l1_masked_sum_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "odvae_l1_masked_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "odvae_colsum_workspace_bytes": (_Z, [_L, _I]),
+    "odvae_colsum_f32": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
+    "odvae_grad_norm_f32": (_I, [_P, _L, _F, _P, _P, _Z, _P]),
+    "odvae_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P]),
+    "odvae_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    """libodvae_hip.so is missing, stale or a kernel call failed."""
+
+
+_lib = None
+
+
+def header_symbols(path=HEADER_PATH):
+    """Function names declared in include/odvae_hip.h."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(odvae_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """dlopen the in-tree library and declare every prototype.  Raises HipLibraryError when it is absent
+    (build it with `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "HIP kernel library %s not found; run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the OD-VAE hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.odvae_abi_version() != 1:
+        raise HipLibraryError("ABI version mismatch: library %d, binding 1" % lib.odvae_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().odvae_last_error().decode("utf-8", "replace")
+        raise HipLibraryError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream, as an integer for ctypes."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError(
+                "OD-VAE HIP op called with a %s tensor: the hot path runs only on a HIP device (no CPU fallback)" % t.device)
+        if t is not None and t.dtype != torch.float32:
+            raise HipLibraryError("OD-VAE HIP op needs float32 tensors, got %s" % t.dtype)
+
+
+class _Workspace:
+    """One grow-only scratch buffer per device; kernels on one stream use it back to back."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 16384)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b.data_ptr(), b.numel()
+
+
+workspace = _Workspace()

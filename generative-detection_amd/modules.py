@@ -1,0 +1,233 @@
+"""Encoder / Decoder of the KL autoencoder, built from the HIP ops.
+
+Module tree, parameter names, shapes and initialisation follow [UPSTREAM] CompVis latent-diffusion
+ldm/modules/diffusionmodules/model.py (Encoder, Decoder, ResnetBlock, AttnBlock, Normalize, Upsample,
+Downsample) as the reference subclasses them in src/modules/autoencodermodules/feat_encoder.py:4-6 and
+feat_decoder.py:4-6, so a reference checkpoint's state_dict loads unchanged.
+torch.nn.Conv2d / GroupNorm objects are used as parameter containers only (default init, OIHW weights);
+their forward is never called -- all arithmetic goes through generative-detection_amd/ops.py.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Normalize(nn.GroupNorm):
+    """GroupNorm(32 groups, eps 1e-6, affine); swish=True fuses nonlinearity(x) = x*sigmoid(x)."""
+
+    def __init__(self, channels, num_groups=32):
+        super().__init__(num_groups=num_groups, num_channels=channels, eps=1e-6, affine=True)
+
+    def forward(self, x, swish=False):
+        return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, swish)
+
+
+class Conv3x3(nn.Conv2d):
+    """3x3 convolution; mode 0 = stride 1 pad 1, 1 = Downsample form, 2 = Upsample form."""
+
+    def __init__(self, cin, cout, mode=0):
+        stride, pad = (2, 0) if mode == 1 else (1, 1)
+        super().__init__(cin, cout, kernel_size=3, stride=stride, padding=pad)
+        self.mode = mode
+
+    def forward(self, x, residual=None):
+        return ops.conv3x3(x, self.weight, self.bias, residual, self.mode)
+
+
+class Conv1x1(nn.Conv2d):
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x, residual=None):
+        return ops.conv1x1(x, self.weight, self.bias, residual)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, with_conv=True):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Upsample without conv is not on the OD-VAE path (resamp_with_conv=True)")
+        self.with_conv = with_conv
+        self.conv = Conv3x3(channels, channels, mode=2)
+
+    def forward(self, x):
+        return self.conv(x)  # nearest 2x is folded into the conv's input gather
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, with_conv=True):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Downsample without conv is not on the OD-VAE path (resamp_with_conv=True)")
+        self.with_conv = with_conv
+        self.conv = Conv3x3(channels, channels, mode=1)
+
+    def forward(self, x):
+        return self.conv(x)  # pad (0,1,0,1) + stride 2 inside the kernel
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        if dropout != 0.0:
+            raise NotImplementedError("ResnetBlock dropout > 0 is not used by the OD-VAE configs (ddconfig.dropout: 0.0)")
+        if temb_channels > 0:
+            raise NotImplementedError("timestep embedding is not part of the autoencoder path (temb_ch = 0)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.use_conv_shortcut = conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv3x3(in_channels, out_channels)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = Conv3x3(out_channels, out_channels)
+        if in_channels != out_channels:
+            if conv_shortcut:
+                self.conv_shortcut = Conv3x3(in_channels, out_channels)
+            else:
+                self.nin_shortcut = Conv1x1(in_channels, out_channels)
+
+    def forward(self, x, temb=None):
+        h = self.conv1(self.norm1(x, swish=True))
+        h = self.norm2(h, swish=True)
+        if self.in_channels != self.out_channels:
+            x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
+        return self.conv2(h, residual=x)  # x + h in the conv epilogue
+
+
+class AttnBlock(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = Conv1x1(in_channels, in_channels)
+        self.k = Conv1x1(in_channels, in_channels)
+        self.v = Conv1x1(in_channels, in_channels)
+        self.proj_out = Conv1x1(in_channels, in_channels)
+
+    def forward(self, x):
+        h = self.norm(x)
+        # one [C -> 3C] projection instead of three reads of h
+        w = torch.cat([self.q.weight, self.k.weight, self.v.weight], dim=0)
+        b = torch.cat([self.q.bias, self.k.bias, self.v.bias], dim=0)
+        qkv = ops.conv1x1(h, w, b)
+        o = ops.attention_qkv(qkv)
+        return self.proj_out(o, residual=x)
+
+
+def make_attn(in_channels, attn_type="vanilla"):
+    if attn_type == "none":
+        return nn.Identity()
+    if attn_type != "vanilla":
+        raise NotImplementedError("attn_type %r: only 'vanilla' is on the OD-VAE path" % attn_type)
+    return AttnBlock(in_channels)
+
+
+class Encoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        if use_linear_attn:
+            attn_type = "linear"
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = Conv3x3(in_channels, ch)
+        curr_res = resolution
+        widths = [ch * m for m in (1,) + tuple(ch_mult)]
+        self.in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for level in range(self.num_resolutions):
+            block_in, block_out = widths[level], widths[level + 1]
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), nn.ModuleList()
+            for _ in range(num_res_blocks):
+                stage.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out,
+                                               temb_channels=self.temb_ch, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    stage.attn.append(make_attn(block_in, attn_type))
+            if level != self.num_resolutions - 1:
+                stage.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res //= 2
+            self.down.append(stage)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv3x3(block_in, 2 * z_channels if double_z else z_channels)
+
+    def forward(self, x):
+        h = self.conv_in(x)
+        for level, stage in enumerate(self.down):
+            for i, block in enumerate(stage.block):
+                h = block(h)
+                if len(stage.attn) > 0:
+                    h = stage.attn[i](h)
+            if level != self.num_resolutions - 1:
+                h = stage.downsample(h)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        return self.conv_out(self.norm_out(h, swish=True))
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
+                 use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+        super().__init__()
+        if use_linear_attn:
+            attn_type = "linear"
+        if tanh_out:
+            raise NotImplementedError("tanh_out is not used by the OD-VAE configs")
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.give_pre_end, self.tanh_out = give_pre_end, tanh_out
+        block_in = ch * ch_mult[-1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = Conv3x3(z_channels, block_in)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        stages = []
+        for level in reversed(range(self.num_resolutions)):
+            block_out = ch * ch_mult[level]
+            stage = nn.Module()
+            stage.block, stage.attn = nn.ModuleList(), nn.ModuleList()
+            for _ in range(num_res_blocks + 1):
+                stage.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out,
+                                               temb_channels=self.temb_ch, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    stage.attn.append(make_attn(block_in, attn_type))
+            if level != 0:
+                stage.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res *= 2
+            stages.insert(0, stage)  # index == resolution level, as upstream
+        self.up = nn.ModuleList(stages)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv3x3(block_in, out_ch)
+
+    def forward(self, z):
+        self.last_z_shape = z.shape
+        h = self.conv_in(z)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        for level in reversed(range(self.num_resolutions)):
+            stage = self.up[level]
+            for i, block in enumerate(stage.block):
+                h = block(h)
+                if len(stage.attn) > 0:
+                    h = stage.attn[i](h)
+            if level != 0:
+                h = stage.upsample(h)
+        if self.give_pre_end:
+            return h
+        return self.conv_out(self.norm_out(h, swish=True))

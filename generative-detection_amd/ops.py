@@ -1,0 +1,418 @@
+"""torch.autograd.Function wrappers around the C ABI kernels (include/odvae_hip.h).
+
+Activations are logical NCHW tensors in channels_last memory, i.e. NHWC in HBM; conv weights stay OIHW
+parameters (checkpoint interchange with the reference) and are repacked per call.
+torch supplies device memory, the current stream and autograd bookkeeping; every FLOP and every byte
+of the hot path moves through libodvae_hip.so.  No CPU fallback exists.
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib as _lib
+
+CL = torch.channels_last
+
+
+def _L():
+    return _lib.load()
+
+
+def _cl(t):
+    """NHWC-in-memory view of a logical NCHW tensor (copy only if the caller handed us another layout)."""
+    _lib.require_device(t)
+    if t.dim() != 4:
+        raise ValueError("expected a 4-d NCHW tensor, got shape %s" % (tuple(t.shape),))
+    n, c, h, w = t.shape
+    if t.stride() == (h * w * c, 1, w * c, c):
+        return t
+    out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device, memory_format=CL)
+    out.copy_(t)
+    if out.stride() != (h * w * c, 1, w * c, c):  # degenerate sizes: force the canonical NHWC strides
+        out = out.as_strided((n, c, h, w), (h * w * c, 1, w * c, c))
+    return out
+
+
+def _new_cl(n, c, h, w, like):
+    t = torch.empty((n, h, w, c), dtype=torch.float32, device=like.device)
+    return t.permute(0, 3, 1, 2)
+
+
+def _ws(nbytes, like):
+    return _lib.workspace.get(nbytes, like.device)
+
+
+# ------------------------------------------------------------------------------------------------------
+# 3x3 convolution family
+# ------------------------------------------------------------------------------------------------------
+def pack_conv3x3(weight, want_fwd=True, want_dgrad=False):
+    """OIHW parameter -> kernel packs (see conv3x3_f32.hip)."""
+    L = _L()
+    w = weight.detach().contiguous()
+    _lib.require_device(w)
+    cout, cin = w.shape[0], w.shape[1]
+    fwd = dgr = None
+    if want_fwd:
+        fwd = torch.empty(L.odvae_conv3x3_pack_floats(cin, cout), dtype=torch.float32, device=w.device)
+    if want_dgrad:
+        dgr = torch.empty(L.odvae_conv3x3_pack_floats(cout, cin), dtype=torch.float32, device=w.device)
+    _lib.check(L.odvae_conv3x3_pack_f32(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()),
+               "conv3x3_pack")
+    return fwd, dgr
+
+
+def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual):
+    L = _L()
+    n, _, hi, wi = x.shape
+    if mode == 0:
+        ho, wo = hi, wi
+    elif mode == 1:
+        ho, wo = hi // 2, wi // 2
+    else:
+        ho, wo = 2 * hi, 2 * wi
+    y = _new_cl(n, cout, ho, wo, x)
+    _lib.check(L.odvae_conv3x3_f32(mode, x.data_ptr(), n, hi, wi, cin, pack.data_ptr(), cout,
+                                   _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, _lib.stream_ptr()),
+               "conv3x3(mode=%d)" % mode)
+    return y
+
+
+class _Conv3x3(Function):
+    """mode 0: stride 1 pad 1; mode 1: Downsample (pad (0,1,0,1), stride 2); mode 2: Upsample (nearest 2x) + conv."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, mode):
+        x = _cl(x)
+        res = _cl(residual) if residual is not None else None
+        cout, cin = weight.shape[0], weight.shape[1]
+        fwd_pack, _ = pack_conv3x3(weight, True, False)
+        b = bias.detach().contiguous() if bias is not None else None
+        y = _conv3x3_raw(mode, x, fwd_pack, cin, cout, b, res)
+        ctx.mode = mode
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        x, weight = ctx.saved_tensors
+        mode = ctx.mode
+        dy = _cl(dy)
+        cout, cin = weight.shape[0], weight.shape[1]
+        n, _, hi, wi = x.shape
+        _, _, ho, wo = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, dgr = pack_conv3x3(weight, False, True)
+            if mode == 0:
+                dx = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)
+            elif mode == 1:
+                dx = _conv3x3_raw(3, dy, dgr, cout, cin, None, None)
+            else:
+                du = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)  # gradient w.r.t. the upsampled image
+                dx = _new_cl(n, cin, hi, wi, x)
+                _lib.check(L.odvae_upsample2x_bwd_f32(du.data_ptr(), dx.data_ptr(), n, hi, wi, cin, _lib.stream_ptr()),
+                           "upsample2x_bwd")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            need = L.odvae_conv3x3_wgrad_workspace_bytes(mode, n, ho, wo, cin, cout)
+            wp, wn = _ws(need, x)
+            _lib.check(L.odvae_conv3x3_wgrad_f32(mode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,
+                                                 dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
+                       "conv3x3_wgrad(mode=%d)" % mode)
+        dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres, None
+
+
+def conv3x3(x, weight, bias=None, residual=None, mode=0):
+    return _Conv3x3.apply(x, weight, bias, residual, mode)
+
+
+# ------------------------------------------------------------------------------------------------------
+# GEMM-backed ops
+# ------------------------------------------------------------------------------------------------------
+def gemm(ta, tb, m, n, k, alpha, a, lda, sa, b, ldb, sb, c, ldc, sc, bias=None, residual=None, batch=1):
+    """Raw batched GEMM on device pointers held by tensors a, b, c (see gemm_f32.hip)."""
+    L = _L()
+    need = L.odvae_gemm_f32_workspace_bytes(m, n, k, batch)
+    wp, wn = _ws(need, c) if need else (None, 0)
+    _lib.check(L.odvae_gemm_f32(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), lda, sa, b.data_ptr(), ldb, sb,
+                                c.data_ptr(), ldc, sc, _lib.ptr(bias), _lib.ptr(residual), batch, wp, wn,
+                                _lib.stream_ptr()), "gemm_f32")
+
+
+def _colsum(x2d_ptr_tensor, rows, c):
+    L = _L()
+    out = torch.empty(c, dtype=torch.float32, device=x2d_ptr_tensor.device)
+    need = L.odvae_colsum_workspace_bytes(rows, c)
+    wp, wn = _ws(need, out)
+    _lib.check(L.odvae_colsum_f32(x2d_ptr_tensor.data_ptr(), rows, c, out.data_ptr(), wp, wn, _lib.stream_ptr()), "colsum")
+    return out
+
+
+class _Conv1x1(Function):
+    """y[M][Cout] = x[M][Cin] . W[Cout][Cin]^T + b (+ residual), M = N*H*W pixels (NHWC)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        x = _cl(x)
+        res = _cl(residual) if residual is not None else None
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        wt = weight.detach().reshape(cout, cin).contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
+        y = _new_cl(n, cout, h, w, x)
+        m = n * h * w
+        gemm(0, 1, m, cout, cin, 1.0, x, cin, 0, wt, cin, 0, y, cout, 0, b, res)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _cl(dy)
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        m = n * h * w
+        wt = weight.detach().reshape(cout, cin).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _new_cl(n, cin, h, w, x)
+            gemm(0, 0, m, cin, cout, 1.0, dy, cout, 0, wt, cin, 0, dx, cin, 0)
+        if ctx.needs_input_grad[1]:
+            dw2 = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+            gemm(1, 0, cout, cin, m, 1.0, dy, cout, 0, x, cin, 0, dw2, cin, 0)
+            dw = dw2.view(cout, cin, 1, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, m, cout)
+        dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres
+
+
+def conv1x1(x, weight, bias=None, residual=None):
+    return _Conv1x1.apply(x, weight, bias, residual)
+
+
+class _Attention(Function):
+    """Single-head attention over T = H*W tokens from a packed qkv tensor [N, 3C, H, W]:
+    softmax(q k^T * C^-0.5) v  ([UPSTREAM] AttnBlock.forward).  Scores live in HBM (T x T per image)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        L = _L()
+        qkv = _cl(qkv)
+        n, c3, h, w = qkv.shape
+        c = c3 // 3
+        t = h * w
+        scale = float(c) ** -0.5
+        p = torch.empty(n, t, t, dtype=torch.float32, device=qkv.device)
+        o = _new_cl(n, c, h, w, qkv)
+        q = qkv.as_strided((1,), (1,), qkv.storage_offset())
+        k = qkv.as_strided((1,), (1,), qkv.storage_offset() + c)
+        v = qkv.as_strided((1,), (1,), qkv.storage_offset() + 2 * c)
+        sq = t * c3
+        gemm(0, 1, t, t, c, 1.0, q, c3, sq, k, c3, sq, p, t, t * t, batch=n)
+        _lib.check(L.odvae_softmax_rows_f32(p.data_ptr(), p.data_ptr(), n * t, t, scale, _lib.stream_ptr()), "softmax_rows")
+        gemm(0, 0, t, c, t, 1.0, p, t, t * t, v, c3, sq, o, c, t * c, batch=n)
+        ctx.save_for_backward(qkv, p)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        L = _L()
+        qkv, p = ctx.saved_tensors
+        do = _cl(do)
+        n, c3, h, w = qkv.shape
+        c = c3 // 3
+        t = h * w
+        scale = float(c) ** -0.5
+        sq = t * c3
+        q = qkv.as_strided((1,), (1,), qkv.storage_offset())
+        k = qkv.as_strided((1,), (1,), qkv.storage_offset() + c)
+        v = qkv.as_strided((1,), (1,), qkv.storage_offset() + 2 * c)
+        dqkv = _new_cl(n, c3, h, w, qkv)
+        dq = dqkv.as_strided((1,), (1,), dqkv.storage_offset())
+        dk = dqkv.as_strided((1,), (1,), dqkv.storage_offset() + c)
+        dv = dqkv.as_strided((1,), (1,), dqkv.storage_offset() + 2 * c)
+        # dV = P^T dO
+        gemm(1, 0, t, c, t, 1.0, p, t, t * t, do, c, t * c, dv, c3, sq, batch=n)
+        # dP = dO V^T, then dS in place
+        dp = torch.empty_like(p)
+        gemm(0, 1, t, t, c, 1.0, do, c, t * c, v, c3, sq, dp, t, t * t, batch=n)
+        _lib.check(L.odvae_softmax_rows_bwd_f32(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), n * t, t, scale,
+                                                _lib.stream_ptr()), "softmax_rows_bwd")
+        # dQ = dS K ; dK = dS^T Q
+        gemm(0, 0, t, c, t, 1.0, dp, t, t * t, k, c3, sq, dq, c3, sq, batch=n)
+        gemm(1, 0, t, c, t, 1.0, dp, t, t * t, q, c3, sq, dk, c3, sq, batch=n)
+        return dqkv
+
+
+def attention_qkv(qkv):
+    return _Attention.apply(qkv)
+
+
+# ------------------------------------------------------------------------------------------------------
+# GroupNorm (+ swish)
+# ------------------------------------------------------------------------------------------------------
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, swish):
+        L = _L()
+        x = _cl(x)
+        n, c, h, w = x.shape
+        g = gamma.detach().contiguous()
+        b = beta.detach().contiguous()
+        y = _new_cl(n, c, h, w, x)
+        mean = torch.empty(n, groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(n, groups, dtype=torch.float32, device=x.device)
+        wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, groups), x)
+        _lib.check(L.odvae_groupnorm_fwd_f32(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps),
+                                             int(swish), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn,
+                                             _lib.stream_ptr()), "groupnorm_fwd")
+        ctx.groups, ctx.swish = groups, int(swish)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = _cl(dy)
+        n, c, h, w = x.shape
+        dx = _new_cl(n, c, h, w, x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        g = gamma.detach().contiguous()
+        b = beta.detach().contiguous()
+        wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, ctx.groups), x)
+        _lib.check(L.odvae_groupnorm_bwd_f32(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(),
+                                             b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(),
+                                             dg.data_ptr(), db.data_ptr(), wp, wn, _lib.stream_ptr()), "groupnorm_bwd")
+        return dx, dg, db, None, None, None
+
+
+def group_norm(x, gamma, beta, groups=32, eps=1e-6, swish=False):
+    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish)
+
+
+# ------------------------------------------------------------------------------------------------------
+# input rescale, posterior, reconstruction term
+# ------------------------------------------------------------------------------------------------------
+def rescale_minmax(x_nchw):
+    """2(x-min)/(max-min)-1 over the whole local batch (src/models/autoencoder.py:434-436); returns NHWC memory."""
+    L = _L()
+    _lib.require_device(x_nchw)
+    x = x_nchw.detach().contiguous()
+    n, c, h, w = x.shape
+    y = _new_cl(n, c, h, w, x)
+    mm = torch.empty(2, dtype=torch.float32, device=x.device)
+    wp, wn = _ws(16384, x)
+    _lib.check(L.odvae_rescale_minmax_f32(x.data_ptr(), y.data_ptr(), n, c, h * w, mm.data_ptr(), wp, wn,
+                                          _lib.stream_ptr()), "rescale_minmax")
+    return y
+
+
+class _GaussianSample(Function):
+    @staticmethod
+    def forward(ctx, moments, eps):
+        L = _L()
+        moments = _cl(moments)
+        eps = _cl(eps)
+        n, c2, h, w = moments.shape
+        cz = c2 // 2
+        z = _new_cl(n, cz, h, w, moments)
+        _lib.check(L.odvae_gaussian_sample_f32(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), n, h * w, cz,
+                                               _lib.stream_ptr()), "gaussian_sample")
+        ctx.save_for_backward(moments, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = _L()
+        moments, eps = ctx.saved_tensors
+        dz = _cl(dz)
+        n, c2, h, w = moments.shape
+        dm = _new_cl(n, c2, h, w, moments)
+        _lib.check(L.odvae_gaussian_bwd_f32(moments.data_ptr(), eps.data_ptr(), dz.data_ptr(), None, dm.data_ptr(),
+                                            n, h * w, c2 // 2, _lib.stream_ptr()), "gaussian_bwd(sample)")
+        return dm, None
+
+
+class _GaussianKL(Function):
+    @staticmethod
+    def forward(ctx, moments):
+        L = _L()
+        moments = _cl(moments)
+        n, c2, h, w = moments.shape
+        kl = torch.empty(n, dtype=torch.float32, device=moments.device)
+        _lib.check(L.odvae_gaussian_kl_f32(moments.data_ptr(), kl.data_ptr(), n, h * w, c2 // 2, _lib.stream_ptr()),
+                   "gaussian_kl")
+        ctx.save_for_backward(moments)
+        return kl
+
+    @staticmethod
+    def backward(ctx, dkl):
+        L = _L()
+        (moments,) = ctx.saved_tensors
+        n, c2, h, w = moments.shape
+        dkl = dkl.contiguous()
+        dm = _new_cl(n, c2, h, w, moments)
+        _lib.check(L.odvae_gaussian_bwd_f32(moments.data_ptr(), None, None, dkl.data_ptr(), dm.data_ptr(),
+                                            n, h * w, c2 // 2, _lib.stream_ptr()), "gaussian_bwd(kl)")
+        return dm
+
+
+def gaussian_sample(moments, eps):
+    return _GaussianSample.apply(moments, eps)
+
+
+def gaussian_kl(moments):
+    return _GaussianKL.apply(moments)
+
+
+class _L1MaskedSum(Function):
+    """per-sample sum |x*m - xr*m| (contperceptual.py:137 with the mask_2d_bbox products of :252-255 folded in)."""
+
+    @staticmethod
+    def forward(ctx, x, xr, mask):
+        L = _L()
+        x = _cl(x)
+        xr = _cl(xr)
+        n, c, h, w = x.shape
+        m = mask.detach().reshape(n, h * w).contiguous() if mask is not None else None
+        _lib.require_device(m)
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+        wp, wn = _ws(n * 1024, x)
+        _lib.check(L.odvae_l1_masked_sum_f32(x.data_ptr(), xr.data_ptr(), _lib.ptr(m), out.data_ptr(), n, h * w, c,
+                                             wp, wn, _lib.stream_ptr()), "l1_masked_sum")
+        ctx.save_for_backward(x, xr, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _L()
+        x, xr, m = ctx.saved_tensors
+        n, c, h, w = x.shape
+        g = g.contiguous()
+        dxr = _new_cl(n, c, h, w, x)
+        _lib.check(L.odvae_l1_masked_bwd_f32(x.data_ptr(), xr.data_ptr(), _lib.ptr(m), g.data_ptr(), dxr.data_ptr(),
+                                             n, h * w, c, _lib.stream_ptr()), "l1_masked_bwd")
+        return None, dxr, None
+
+
+def l1_masked_sum(x, xr, mask=None):
+    return _L1MaskedSum.apply(x, xr, mask)
+
+
+def nhwc_to_nchw(x):
+    """Contiguous NCHW copy of an NHWC-in-memory tensor (hand-off to NCHW consumers)."""
+    L = _L()
+    x = _cl(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    _lib.check(L.odvae_nhwc_to_nchw_f32(x.data_ptr(), y.data_ptr(), n, c, h * w, _lib.stream_ptr()), "nhwc_to_nchw")
+    return y

@@ -1,0 +1,120 @@
+/* libodvae_hip.so -- C ABI of the MI355X (gfx950) kernels behind the OD-VAE autoencoder training step.
+ *
+ * The reference (tanushreebanerjee/generative-detection) has no FFI of its own: its hot path calls
+ * torch ops from Python ([UPSTREAM] ldm/modules/diffusionmodules/model.py through
+ * src/modules/autoencodermodules/feat_encoder.py:4, feat_decoder.py:4; src/models/autoencoder.py;
+ * src/util/distributions.py; src/modules/losses/contperceptual.py).  Each entry point below names the
+ * torch call it stands in for.  The host side binds these with ctypes
+ * (generative-detection_amd/lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP global memory) unless it says "host";
+ *   - tensors are f32, activations are NHWC ([N][H][W][C], channels contiguous), conv weights OIHW;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work, they
+ *     never synchronise the device and never allocate;
+ *   - scratch comes from the caller: `workspace`/`workspace_bytes`, sized by the *_workspace_bytes query;
+ *   - return value: 0 on success, ODVAE_ERR_* otherwise; odvae_last_error() holds the message.
+ */
+#ifndef ODVAE_HIP_H
+#define ODVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODVAE_OK 0
+#define ODVAE_ERR_ARG 1
+#define ODVAE_ERR_WORKSPACE 2
+#define ODVAE_ERR_HIP 3
+
+/* ---- runtime.cpp ------------------------------------------------------------------------------- */
+const char* odvae_last_error(void);   /* host string, thread-local */
+int odvae_abi_version(void);          /* == 1 for this header */
+const char* odvae_target_arch(void);  /* "gfx950" */
+
+/* ---- gemm_f32.hip: torch.nn.Conv2d(k=1) / torch.bmm ---------------------------------------------
+ * C[b] = alpha * op(A[b]) * op(B[b]) (+ bias[col]) (+ residual[b]); row-major;
+ * transA=0: A is [M][K]; transA=1: A is stored [K][M]; transB=0: B is [K][N]; transB=1: B is stored [N][K].
+ * Stands in for the 1x1 convolutions (nin_shortcut, AttnBlock q/k/v/proj_out, quant_conv_obj/pose,
+ * post_quant_conv: src/models/autoencoder.py:88-90,179-180) and AttnBlock's torch.bmm products. */
+size_t odvae_gemm_f32_workspace_bytes(int M, int N, int K, int batch);
+int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                   const float* A, int lda, int64_t strideA,
+                   const float* B, int ldb, int64_t strideB,
+                   float* C, int ldc, int64_t strideC,
+                   const float* bias, const float* residual, int batch,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- conv3x3_f32.hip: torch.nn.Conv2d(k=3) in ResnetBlock / Downsample / Upsample / conv_in / conv_out
+ * Weight packs: reduction axis padded to odvae_conv3x3_pack_reduce_pad(), output axis to
+ * odvae_conv3x3_pack_out_pad(); a pack has odvae_conv3x3_pack_floats(c_reduce, c_out) floats.
+ * odvae_conv3x3_pack_f32 turns OIHW into the forward pack (reduce=Cin,out=Cout) and/or the
+ * data-gradient pack (reduce=Cout,out=Cin, taps flipped); either output may be NULL. */
+int odvae_conv3x3_pack_reduce_pad(int c_reduce);
+int odvae_conv3x3_pack_out_pad(int c_out);
+size_t odvae_conv3x3_pack_floats(int c_reduce, int c_out);
+int odvae_conv3x3_pack_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
+/* mode 0: stride 1 pad 1 (ResnetBlock.conv1/conv2, conv_in, conv_out)
+ * mode 1: F.pad(x,(0,1,0,1)) + stride 2 pad 0 (Downsample.forward)      Ho = Hi/2
+ * mode 2: F.interpolate(scale 2, nearest) + stride 1 pad 1 (Upsample)   Ho = 2*Hi
+ * mode 3: data gradient of mode 1 (x = dy, y = dx, wpk = dgrad pack)    Ho = 2*Hi
+ * The data gradient of mode 0 is mode 0 with the dgrad pack. */
+int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
+                      const float* wpk, int Cout, const float* bias, const float* residual,
+                      float* y, int Ho, int Wo, void* stream);
+
+/* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2)
+ * dw is OIHW [Cout][Cin][3][3], overwritten; dbias [Cout] or NULL. */
+size_t odvae_conv3x3_wgrad_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout);
+int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, int Hi, int Wi, int Cin,
+                            int Ho, int Wo, int Cout, float* dw, float* dbias,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- groupnorm.hip: Normalize = GroupNorm(32, C, eps=1e-6) followed by x*sigmoid(x) -----------------
+ * x,y: [N][HW][C]; mean,rstd: [N][G]; swish: 0 identity, 1 x*sigmoid(x). */
+size_t odvae_groupnorm_workspace_bytes(int N, int HW, int C, int G);
+int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                            float eps, int swish, float* y, float* mean, float* rstd,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
+                            const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
+                            float* dx, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- elementwise.hip ------------------------------------------------------------------------------ */
+/* torch.nn.functional.softmax(scale * x, dim=-1) over rows (AttnBlock); y may alias x */
+int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, float scale, void* stream);
+int odvae_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, void* stream);
+/* backward of F.interpolate(scale_factor=2, mode="nearest"): dx[N][H][W][C] from du[N][2H][2W][C] */
+int odvae_upsample2x_bwd_f32(const float* du, float* dx, int N, int H, int W, int C, void* stream);
+/* PoseAutoencoder._rescale (src/models/autoencoder.py:434-436): NCHW in, NHWC out; workspace >= 8 KiB */
+int odvae_rescale_minmax_f32(const float* x_nchw, float* y_nhwc, int N, int C, int HW, float* minmax_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* DiagonalGaussianDistribution (src/util/distributions.py:5-41): moments [N][HW][2*Cz] */
+int odvae_gaussian_sample_f32(const float* moments, const float* eps, float* z, int N, int HW, int Cz, void* stream);
+int odvae_gaussian_kl_f32(const float* moments, float* kl, int N, int HW, int Cz, void* stream);
+int odvae_gaussian_bwd_f32(const float* moments, const float* eps, const float* dz, const float* dkl,
+                           float* dmoments, int N, int HW, int Cz, void* stream);
+/* PoseLoss._get_rec_loss pixel term with mask_2d_bbox applied (contperceptual.py:137,252-255):
+ * out[n] = sum |x*m - xr*m|; workspace >= N*1 KiB */
+int odvae_l1_masked_sum_f32(const float* x, const float* xr, const float* mask, float* out, int N, int HW, int C,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int odvae_l1_masked_bwd_f32(const float* x, const float* xr, const float* mask, const float* g, float* dxr,
+                            int N, int HW, int C, void* stream);
+/* bias gradient of a 1x1 convolution: out[c] = sum_rows x[row][c] */
+size_t odvae_colsum_workspace_bytes(int64_t rows, int C);
+int odvae_colsum_f32(const float* x, int64_t rows, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.nn.utils.clip_grad_norm_ over one flat arena: out[0] = norm, out[1] = clip coefficient; workspace >= 4 KiB */
+int odvae_grad_norm_f32(const float* g, int64_t n, float max_norm, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adam step (src/models/autoencoder.py:365-377) over flat arenas; clip = odvae_grad_norm_f32 output or NULL */
+int odvae_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, int step, const float* clip, void* stream);
+int odvae_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODVAE_HIP_H */

@@ -1,0 +1,280 @@
+"""Per-kernel parity: HIP path (through the C ABI) vs torch CPU fp32 functional ops on the same seeded inputs.
+Tolerance: max|hip - ref| <= TOL * max(1, max|ref|), TOL = 2e-4 forward / 5e-4 backward unless noted
+(fp32 with different summation order; K up to a few thousand)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-4
+BWD_TOL = 5e-4
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert err <= tol * ref, "%s: max err %.3e > %.1e * %.3e" % (what, err, tol, ref)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k,batch", [(128, 128, 64, 1), (200, 72, 52, 3), (16, 16, 512, 2), (4, 260, 36, 1)])
+def test_gemm(hip_lib, ta, tb, m, n, k, batch):
+    from odvae_amd import ops
+    if ta and m % 4:
+        pytest.skip("transA needs M % 4 == 0")
+    if not tb and n % 4:
+        pytest.skip("transB=0 needs N % 4 == 0")
+    g = torch.Generator().manual_seed(m * 131 + n * 17 + k + batch + ta * 2 + tb)
+    a = torch.randn(batch, *((k, m) if ta else (m, k)), generator=g)
+    b = torch.randn(batch, *((n, k) if tb else (k, n)), generator=g)
+    bias = torch.randn(n, generator=g)
+    res = torch.randn(batch, m, n, generator=g)
+    ref = 0.5 * torch.bmm(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b) + bias + res
+    ad, bd, biasd, resd = a.to(dev()), b.to(dev()), bias.to(dev()), res.to(dev())
+    c = torch.full((batch, m, n), float("nan"), device=dev())
+    ops.gemm(ta, tb, m, n, k, 0.5, ad, a.shape[2], a.shape[1] * a.shape[2], bd, b.shape[2], b.shape[1] * b.shape[2],
+             c, n, m * n, biasd, resd, batch)
+    close(c, ref, FWD_TOL * math.sqrt(k / 32), "gemm")
+
+
+def test_gemm_splitk(hip_lib):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(7)
+    m, n, k = 64, 96, 16384
+    a = torch.randn(k, m, generator=g)  # stored [K][M] (transA), the wgrad shape
+    b = torch.randn(k, n, generator=g)
+    ref = (a.double().t() @ b.double()).float()
+    assert hip_lib.odvae_gemm_f32_workspace_bytes(m, n, k, 1) > 0
+    c = torch.empty(m, n, device=dev())
+    ops.gemm(1, 0, m, n, k, 1.0, a.to(dev()), m, 0, b.to(dev()), n, 0, c, n, 0)
+    close(c, ref, 1e-5 * math.sqrt(k), "gemm split-K")
+
+
+# ------------------------------------------------------------------------------------------------------
+def ref_conv(mode, x, w, b):
+    if mode == 0:
+        return F.conv2d(x, w, b, stride=1, padding=1)
+    if mode == 1:
+        return F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2, padding=0)
+    return F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, stride=1, padding=1)
+
+
+CONV_CASES = [
+    # mode, N, Cin, Cout, H, W
+    (0, 2, 32, 64, 24, 16),
+    (0, 1, 3, 128, 16, 32),
+    (0, 2, 128, 3, 16, 16),
+    (0, 2, 16, 32, 4, 4),
+    (0, 1, 64, 160, 20, 12),
+    (0, 1, 256, 256, 8, 8),
+    (1, 2, 32, 32, 16, 32),
+    (1, 1, 128, 128, 8, 8),
+    (2, 2, 32, 32, 8, 16),
+    (2, 1, 128, 128, 4, 4),
+]
+
+
+@pytest.mark.parametrize("mode,n,cin,cout,h,w", CONV_CASES)
+def test_conv3x3_fwd_bwd(hip_lib, mode, n, cin, cout, h, w):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(1000 * mode + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = ref_conv(mode, xr, wr, br)
+    res = torch.randn(y_ref.shape, generator=g)
+    resr = res.clone().requires_grad_(True)
+    y_ref = y_ref + resr
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+
+    xd = x.to(dev()).requires_grad_(True)
+    wd = wt.to(dev()).requires_grad_(True)
+    bd = b.to(dev()).requires_grad_(True)
+    resd = res.to(dev()).requires_grad_(True)
+    y = ops.conv3x3(xd, wd, bd, resd, mode)
+    close(y, y_ref, FWD_TOL, "conv fwd")
+    y.backward(gy.to(dev()))
+    close(xd.grad, xr.grad, BWD_TOL, "conv dx")
+    close(wd.grad, wr.grad, BWD_TOL * math.sqrt(n * h * w / 64), "conv dw")
+    close(bd.grad, br.grad, BWD_TOL * math.sqrt(n * h * w / 64), "conv db")
+    close(resd.grad, resr.grad, 1e-6, "conv dres")
+
+
+def test_conv3x3_no_bias_no_res(hip_lib):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 32, 16, 16, generator=g)
+    wt = torch.randn(32, 32, 3, 3, generator=g) / 17
+    y = ops.conv3x3(x.to(dev()), wt.to(dev()))
+    close(y, F.conv2d(x, wt, None, 1, 1), FWD_TOL, "conv plain")
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,h,w,swish", [(2, 32, 8, 8, True), (2, 64, 16, 8, False), (3, 128, 12, 20, True),
+                                             (1, 512, 16, 16, True), (2, 256, 4, 4, False)])
+def test_groupnorm(hip_lib, n, c, h, w, swish):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    gamma = torch.randn(c, generator=g)
+    beta = torch.randn(c, generator=g)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    y_ref = F.group_norm(xr, 32, gr, br, eps=1e-6)
+    if swish:
+        y_ref = y_ref * torch.sigmoid(y_ref)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, gd, bd = (t.to(dev()).requires_grad_(True) for t in (x, gamma, beta))
+    y = ops.group_norm(xd, gd, bd, 32, 1e-6, swish)
+    close(y, y_ref, FWD_TOL, "gn fwd")
+    y.backward(gy.to(dev()))
+    close(xd.grad, xr.grad, BWD_TOL, "gn dx")
+    close(gd.grad, gr.grad, BWD_TOL * 4, "gn dgamma")
+    close(bd.grad, br.grad, BWD_TOL * 4, "gn dbeta")
+
+
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 64, 8, 8), (1, 128, 128, 16, 16), (3, 32, 16, 4, 4), (2, 16, 16, 4, 4)])
+def test_conv1x1(hip_lib, n, cin, cout, h, w):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(cin * cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    xr, wr, br, rr = (t.clone().requires_grad_(True) for t in (x, wt, b, res))
+    y_ref = F.conv2d(xr, wr, br) + rr
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, wd, bd, rd = (t.to(dev()).requires_grad_(True) for t in (x, wt, b, res))
+    y = ops.conv1x1(xd, wd, bd, rd)
+    close(y, y_ref, FWD_TOL, "1x1 fwd")
+    y.backward(gy.to(dev()))
+    close(xd.grad, xr.grad, BWD_TOL, "1x1 dx")
+    close(wd.grad, wr.grad, BWD_TOL * 2, "1x1 dw")
+    close(bd.grad, br.grad, BWD_TOL * 2, "1x1 db")
+    close(rd.grad, rr.grad, 1e-6, "1x1 dres")
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 32, 4, 4), (2, 64, 16, 16), (1, 256, 8, 16)])
+def test_attention(hip_lib, n, c, h, w):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(c + h * w)
+    qkv = torch.randn(n, 3 * c, h, w, generator=g)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr[:, :c], qr[:, c:2 * c], qr[:, 2 * c:]
+    t = h * w
+    w_ = torch.bmm(q.reshape(n, c, t).permute(0, 2, 1), k.reshape(n, c, t)) * (c ** -0.5)
+    w_ = F.softmax(w_, dim=2)
+    o_ref = torch.bmm(v.reshape(n, c, t), w_.permute(0, 2, 1)).reshape(n, c, h, w)
+    go = torch.randn(o_ref.shape, generator=g)
+    o_ref.backward(go)
+    qd = qkv.to(dev()).requires_grad_(True)
+    o = ops.attention_qkv(qd)
+    close(o, o_ref, FWD_TOL, "attn fwd")
+    o.backward(go.to(dev()))
+    close(qd.grad, qr.grad, BWD_TOL, "attn dqkv")
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_rescale_minmax(hip_lib):
+    from odvae_amd import ops
+    x = torch.rand(3, 3, 20, 12, generator=torch.Generator().manual_seed(3))
+    ref = 2.0 * (x - x.min()) / (x.max() - x.min()) - 1.0
+    y = ops.rescale_minmax(x.to(dev()))
+    assert y.shape == x.shape and y.stride() == (20 * 12 * 3, 1, 12 * 3, 3)
+    close(y, ref, 1e-6, "rescale")
+
+
+def test_gaussian(hip_lib):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(11)
+    mom = torch.randn(3, 8, 4, 4, generator=g) * 3
+    mom[0, 5, 0, 0] = 25.0   # beyond the clamp
+    mom[1, 6, 1, 1] = -40.0
+    eps = torch.randn(3, 4, 4, 4, generator=g)
+    mr = mom.clone().requires_grad_(True)
+    mean, logvar = torch.chunk(mr, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    z_ref = mean + torch.exp(0.5 * logvar) * eps
+    kl_ref = 0.5 * torch.sum(mean ** 2 + torch.exp(logvar) - 1.0 - logvar, dim=[1, 2, 3])
+    gz = torch.randn(z_ref.shape, generator=g)
+    gk = torch.randn(3, generator=g)
+    (z_ref * gz).sum().backward(retain_graph=True)
+    g1 = mr.grad.clone(); mr.grad = None
+    (kl_ref * gk).sum().backward()
+    g2 = mr.grad.clone()
+    md = mom.to(dev()).requires_grad_(True)
+    z = ops.gaussian_sample(md, eps.to(dev()))
+    close(z, z_ref, 1e-5, "sample")
+    z.backward(gz.to(dev()))
+    close(md.grad, g1, 1e-5, "sample bwd")
+    md.grad = None
+    kl = ops.gaussian_kl(md)
+    close(kl, kl_ref, 1e-5, "kl")
+    kl.backward(gk.to(dev()))
+    close(md.grad, g2, 1e-5, "kl bwd")
+
+
+def test_l1_masked(hip_lib):
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(3, 3, 16, 8, generator=g)
+    xr = torch.randn(3, 3, 16, 8, generator=g).requires_grad_(True)
+    m = (torch.rand(3, 1, 16, 8, generator=g) > 0.3).float()
+    ref = torch.abs(x * m - xr * m).sum(dim=[1, 2, 3])
+    gw = torch.randn(3, generator=g)
+    (ref * gw).sum().backward()
+    xd = x.to(dev())
+    xrd = xr.detach().to(dev()).requires_grad_(True)
+    out = ops.l1_masked_sum(xd, xrd, m.to(dev()))
+    close(out, ref, 1e-5, "l1")
+    (out * gw.to(dev())).sum().backward()
+    close(xrd.grad, xr.grad, 1e-6, "l1 bwd")
+    out2 = ops.l1_masked_sum(xd, xrd, None)
+    close(out2, torch.abs(x - xr).sum(dim=[1, 2, 3]), 1e-5, "l1 nomask")
+
+
+def test_adam_and_norm(hip_lib):
+    from odvae_amd import lib
+    L = hip_lib
+    g = torch.Generator().manual_seed(17)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3, betas=(0.5, 0.9))
+    p = p0.to(dev()); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    out = torch.empty(2, device=dev())
+    ws = torch.empty(4096, device=dev())
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 0.01 * step
+        ref_p.grad = grad.clone()
+        total = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        gd = grad.to(dev())
+        lib.check(L.odvae_grad_norm_f32(gd.data_ptr(), n, 1.0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4, lib.stream_ptr()), "norm")
+        assert abs(out[0].item() - total.item()) <= 1e-5 * total.item()
+        lib.check(L.odvae_adam_step_f32(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.5, 0.9, 1e-8,
+                                        step, out.data_ptr(), lib.stream_ptr()), "adam")
+        close(p, ref_p, 1e-6, "adam step %d" % step)
+
+
+def test_fails_loudly_on_cpu_tensor(hip_lib):
+    from odvae_amd import ops, lib
+    with pytest.raises(lib.HipLibraryError):
+        ops.group_norm(torch.randn(1, 32, 4, 4), torch.ones(32), torch.zeros(32), 32, 1e-6, True)
