@@ -39,8 +39,12 @@ def test_encoder_decoder_match_oracle(hip_lib, which):
     assert rel_err(xd.grad, xr.grad) < 3e-3, "input grad rel err %.3e" % rel_err(xd.grad, xr.grad)
     worst = ("", 0.0)
     ref_params = dict(ref.named_parameters())
+    # some gradients are analytically zero (attention k.bias: softmax is shift-invariant), so errors are
+    # measured against max(|ref grad|, 1e-3 * largest gradient in the net)
+    scale = max(p.grad.abs().max().item() for p in ref_params.values())
     for name, p in net.named_parameters():
-        e = rel_err(p.grad, ref_params[name].grad)
+        r = ref_params[name].grad.double()
+        e = (p.grad.detach().cpu().double() - r).abs().max().item() / max(r.abs().max().item(), 1e-3 * scale)
         if e > worst[1]:
             worst = (name, e)
     assert worst[1] < 3e-3, "param grad %s rel err %.3e" % worst
