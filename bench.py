@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Headline benchmark: VAE training images/s (fwd + bwd + optimizer) at 256x256, z = 16x16x16 (BASELINE.json).
+
+Workload = BASELINE.json configs[1]: configs/autoencoder/pose/autoencoder_kl_16x16x16.yaml (fixture copy under
+tests/golden/), 256x256 synthetic crops, B = 32 per GPU, fp32, rec+KL only (perceptual_weight = 0, disc_factor = 0,
+optimizer 1 skipped), VAE phase.  One process per GPU; N > 1 is launched by torch.distributed.run
+and shards the minibatch (weak scaling) with the bucketed RCCL all-reduce of generative-detection_amd/parallel.py.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every launch of the dominant
+kernel (the 128x128-tile 3x3 implicit-GEMM convolution, forward + data-gradient) during the timed steps;
+`cpu_baseline` times the CPU oracle (a port: the reference itself cannot be imported) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+YAML = os.path.join(ROOT, "tests", "golden", "autoencoder_kl_16x16x16.yaml")
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(res, batch=1, steps=1):
+    """Oracle (plain torch on the host cores) on a bounded sample of the same workload: same yaml, same step
+    definition (fwd + bwd + clip + Adam), rec+KL only, at `res` x `res`, batch `batch`."""
+    from odvae_amd import synthetic
+    from oracle.autoencoder import PoseAutoencoder as OraclePA, train_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lat = res // 16
+    mcfg, _ = synthetic.model_config(YAML, latent_hw=lat)
+    p = mcfg.params.to_container()
+    torch.manual_seed(23)
+    ref = OraclePA(p["ddconfig"], dict(p["lossconfig"]["params"]), p["embed_dim"], p["pose_decoder_config"]["params"],
+                   p["pose_encoder_config"]["params"], feat_dims=p["feat_dims"], dropout_prob_init=p["dropout_prob_init"],
+                   dropout_prob_final=p["dropout_prob_final"], dropout_warmup_steps=p["dropout_warmup_steps"],
+                   pose_conditioned_generation_steps=p["pose_conditioned_generation_steps"])
+    ref.learning_rate = 12 * 4.5e-6
+    opts = ref.configure_optimizers()
+    batch_d = synthetic.make_batch(batch, res, seed=23)
+    noise = synthetic.make_noise(batch, lat, seed=24)
+    t0 = time.time()
+    for _ in range(steps):
+        train_batch(ref, opts, batch_d, {0: noise}, optimizer_indices=(0,), clip=1.0)
+    dt = time.time() - t0
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s), B=%d, %dx%d, fp32, rec+KL only, torch %s CPU oracle" % (steps, batch, res, res, torch.__version__)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    from odvae_amd import ops, synthetic
+    from odvae_amd.trainer import Trainer
+
+    torch.manual_seed(23)
+    lat = args.res // 16
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat).to(dev)
+    model.train()
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,))
+    batch = synthetic.make_batch(args.batch, args.res, seed=23 + rank)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}  # inputs resident in HBM
+
+    def step(i):
+        b = dict(batch)
+        b["pose_6d"] = batch["pose_6d"].clone()  # training_step writes yaw into it
+        return trainer.training_batch(b, i)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        ops.KERNEL_EVENTS.enable()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    roof = ops.KERNEL_EVENTS.summary("conv3x3_128x128") if not args.no_kernel_events else None
+    ops.KERNEL_EVENTS.disable()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "VAE train images/s (fwd+bwd+opt) at 256x256 z=16x16x16",
+            "value": args.batch * world * args.steps / elapsed,
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, rec+KL only (discriminator off, optimizer 0), VAE phase"
+                       % (args.res, args.res, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+        }
+        if roof is not None:
+            out["roofline"] = {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "conv3x3_kernel<MODE 0,KC 16,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)",
+                               "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
+                               "algorithmic_gflop_per_launch": roof["gflop_per_launch"],
+                               "share_of_step_time": roof["total_ms"] / (ms * args.steps)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.res)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -344,9 +344,43 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+// ---- y = x * m[n][hw] (mask_2d_bbox products, contperceptual.py:252-255); its own backward with x = dy ----
+__global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                       float* __restrict__ y, int64_t npix, int C) {
+  const int64_t total = npix * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    y[idx] = x[idx] * m[idx / C];
+}
+
+// ---- latent mixing: out = z * mask + add (dropout on z_obj, + N(0,1) noise, + enc_pose; autoencoder.py:233-253)
+__global__ __launch_bounds__(256) void latent_combine_kernel(const float* __restrict__ z, const float* __restrict__ mask,
+                                                             const float* __restrict__ add, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = z[i];
+    if (mask) v *= mask[i];
+    if (add) v += add[i];
+    out[i] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int odvae_mul_mask_f32(const float* x, const float* mask, float* y, int64_t npix, int C, void* stream) {
+  ODVAE_CHECK_ARG(x && mask && y && npix > 0 && C > 0, "mul_mask: bad arguments");
+  hipLaunchKernelGGL(mul_mask_kernel, dim3(grid_1d(npix * C)), dim3(256), 0, static_cast<hipStream_t>(stream), x, mask, y, npix, C);
+  ODVAE_LAUNCH_CHECK("mul_mask");
+  return ODVAE_OK;
+}
+
+int odvae_latent_combine_f32(const float* z, const float* mask, const float* add, float* out, int64_t n, void* stream) {
+  ODVAE_CHECK_ARG(z && out && n > 0, "latent_combine: bad arguments");
+  hipLaunchKernelGGL(latent_combine_kernel, dim3(grid_1d(n)), dim3(256), 0, static_cast<hipStream_t>(stream), z, mask, add, out, n);
+  ODVAE_LAUNCH_CHECK("latent_combine");
+  return ODVAE_OK;
+}
 
 int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, float scale, void* stream) {
   ODVAE_CHECK_ARG(x && y && rows > 0 && cols > 0 && cols % 4 == 0, "softmax_rows: need cols %% 4 == 0 (rows=%lld cols=%d)", (long long)rows, cols);

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "odvae_grad_norm_f32": (_I, [_P, _L, _F, _P, _P, _Z, _P]),
     "odvae_adam_step_f32": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P]),
     "odvae_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "odvae_mul_mask_f32": (_I, [_P, _P, _P, _L, _I, _P]),
+    "odvae_latent_combine_f32": (_I, [_P, _P, _P, _P, _L, _P]),
 }
 
 

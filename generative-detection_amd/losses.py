@@ -1,0 +1,324 @@
+"""PoseLoss / LPIPSWithDiscriminator with the reference's interface and log keys.
+
+Mirrors src/modules/losses/contperceptual.py (PoseLoss :26-375) on top of [UPSTREAM]
+ldm/modules/losses/contperceptual.py LPIPSWithDiscriminator (constructor arguments, logvar parameter,
+calculate_adaptive_weight) and taming/modules/losses/vqperceptual.py (adopt_weight, hinge_d_loss, vanilla_d_loss).
+
+Hot-path arithmetic (the per-pixel masked L1 term and its gradient, the image-posterior KL, the PatchGAN and the
+LPIPS-style network) runs in HIP kernels; the O(B) scalar assembly and the pose-head losses use torch ops on
+[B]-sized tensors.  Reference quirks are kept on purpose and marked QUIRK.
+"""
+import math
+import pickle as pkl
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .distributions import DiagonalGaussianDistribution
+from .gan import LPIPSStyle, NLayerDiscriminator, weights_init
+
+POSE_6D_DIM = 4
+LHW_DIM = 3
+FILL_FACTOR_DIM = 1
+PROB_THRESHOLD_OBJ = 0.2
+BACKGROUND_CLASS_IDX = 1  # QUIRK (contperceptual.py:17,228): masks class id 1 ("truck"), not "background" (id 10)
+BBOX_DIM = POSE_6D_DIM + LHW_DIM + FILL_FACTOR_DIM
+
+
+def adopt_weight(weight, global_step, threshold=0, value=0.0):
+    return value if global_step < threshold else weight
+
+
+def hinge_d_loss(logits_real, logits_fake):
+    return 0.5 * (torch.mean(F.relu(1.0 - logits_real)) + torch.mean(F.relu(1.0 + logits_fake)))
+
+
+def vanilla_d_loss(logits_real, logits_fake):
+    return 0.5 * (torch.mean(F.softplus(-logits_real)) + torch.mean(F.softplus(logits_fake)))
+
+
+class SigmoidFocalLoss(nn.Module):
+    """mmdet.models.losses.FocalLoss() defaults (use_sigmoid, gamma 2, alpha 0.25, mean over B*classes) restated in
+    torch ops for class-index targets (contperceptual.py:11,70,179)."""
+
+    def __init__(self, gamma=2.0, alpha=0.25, loss_weight=1.0):
+        super().__init__()
+        self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
+
+    def forward(self, pred, target):
+        num_classes = pred.size(1)
+        onehot = F.one_hot(target.long(), num_classes=num_classes + 1)[:, :num_classes].type_as(pred)
+        p = pred.sigmoid()
+        pt = (1 - p) * onehot + p * (1 - onehot)
+        focal = (self.alpha * onehot + (1 - self.alpha) * (1 - onehot)) * pt.pow(self.gamma)
+        loss = F.binary_cross_entropy_with_logits(pred, onehot, reduction="none") * focal
+        return self.loss_weight * loss.mean()
+
+
+def _elementwise_loss(name, what):
+    if name == "l1":
+        return nn.L1Loss(reduction="none")
+    if name in ("l2", "mse"):
+        return nn.MSELoss(reduction="none")
+    raise ValueError("Invalid %s loss function. Please provide a valid %s loss function in ['l1', 'l2', 'mse']." % (what, what))
+
+
+class LPIPSWithDiscriminator(nn.Module):
+    """[UPSTREAM] ldm LPIPSWithDiscriminator: owns logvar, the LPIPS-style net and the PatchGAN."""
+
+    def __init__(self, disc_start, logvar_init=0.0, kl_weight=1.0, pixelloss_weight=1.0, disc_num_layers=3,
+                 disc_in_channels=3, disc_factor=1.0, disc_weight=1.0, perceptual_weight=1.0, use_actnorm=False,
+                 disc_conditional=False, disc_loss="hinge"):
+        super().__init__()
+        assert disc_loss in ["hinge", "vanilla"]
+        if use_actnorm:
+            raise NotImplementedError("use_actnorm=True is not used by the OD-VAE configs")
+        self.kl_weight = kl_weight
+        self.pixel_weight = pixelloss_weight
+        self.perceptual_loss = LPIPSStyle().eval()
+        self.perceptual_weight = perceptual_weight
+        self.logvar = nn.Parameter(torch.ones(size=()) * logvar_init)
+        self.discriminator = NLayerDiscriminator(input_nc=disc_in_channels, n_layers=disc_num_layers,
+                                                 use_actnorm=use_actnorm).apply(weights_init)
+        self.discriminator_iter_start = disc_start
+        self.disc_loss = hinge_d_loss if disc_loss == "hinge" else vanilla_d_loss
+        self.disc_factor = disc_factor
+        self.discriminator_weight = disc_weight
+        self.disc_conditional = disc_conditional
+
+    def calculate_adaptive_weight(self, nll_loss, g_loss, last_layer=None):
+        if last_layer is None:
+            last_layer = self.last_layer[0]
+        nll_grads = torch.autograd.grad(nll_loss, last_layer, retain_graph=True)[0]
+        g_grads = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0]
+        d_weight = torch.norm(nll_grads) / (torch.norm(g_grads) + 1e-4)
+        d_weight = torch.clamp(d_weight, 0.0, 1e4).detach()
+        return d_weight * self.discriminator_weight
+
+
+class PoseLoss(LPIPSWithDiscriminator):
+    def __init__(self, train_on_yaw=True, kl_weight_obj=1.0, kl_weight_bbox=1e-6, pose_weight=1.0, mask_weight=0.0,
+                 class_weight=1.0, bbox_weight=1.0, fill_factor_weight=1.0, pose_loss_fn=None, mask_loss_fn=None,
+                 encoder_pretrain_steps=0, pose_conditioned_generation_steps=7000, use_mask_loss=True,
+                 use_class_loss=False, use_bbox_loss=False, num_classes=1,
+                 dataset_stats_path="dataset_stats/combined/all.pkl", dataset_stats=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.pose_conditioned_generation_steps = pose_conditioned_generation_steps
+        self.encoder_pretrain_steps = encoder_pretrain_steps
+        self.pose_weight, self.mask_weight = pose_weight, mask_weight
+        self.fill_factor_weight, self.class_weight, self.bbox_weight = fill_factor_weight, class_weight, bbox_weight
+        self.use_mask_loss = use_mask_loss
+        self.num_classes = num_classes
+        self.kl_weight_obj, self.kl_weight_bbox = kl_weight_obj, kl_weight_bbox
+        self.train_on_yaw = train_on_yaw
+        assert pose_loss_fn is not None, "Please provide a pose loss function."
+        assert mask_loss_fn is not None, "Please provide a mask loss function."
+        assert pose_loss_fn in ["l1", "l2", "mse"], "Please provide a valid pose loss function in ['l1', 'l2', 'mse']."
+        self.pose_loss = _elementwise_loss(pose_loss_fn, "pose")
+        self.mask_loss = _elementwise_loss(mask_loss_fn, "mask")
+        if self.train_on_yaw:
+            self.rot_loss_fn = nn.SmoothL1Loss(reduction="none")
+        self.class_loss_fn = SigmoidFocalLoss()
+        self.bbox_loss_fn = nn.MSELoss(reduction="none")
+        self.fill_factor_loss_fn = nn.MSELoss(reduction="none")
+        # `dataset_stats` (a dict) is an extension for runs without the pickle, which the reference does not ship
+        if dataset_stats is None:
+            with open(dataset_stats_path, "rb") as handle:
+                dataset_stats = pkl.load(handle)
+        self.bbox_distribution_dict = self._create_distribution_from_dataset_stats(dataset_stats)
+
+    # ---- priors over the pose-head posterior (contperceptual.py:82-109) -----------------------------------
+    def _create_distribution_from_dataset_stats(self, dataset_stats):
+        fixed = {"yaw": (0.0, math.pi), "t1": (0.0, 1.0), "t2": (0.0, 1.0), "fill_factor": (0.5, math.sqrt(2))}
+        rot_param = "yaw" if self.train_on_yaw else "v3"
+        out = {}
+        for label, stats in dataset_stats.items():
+            means, logvars = torch.zeros(BBOX_DIM), torch.zeros(BBOX_DIM)
+            for idx, key in enumerate(["t1", "t2", "t3", rot_param, "l", "h", "w", "fill_factor"]):
+                if key in fixed:
+                    mean, std_dev = fixed[key]
+                    logvar = 2 * torch.log(torch.tensor(std_dev))
+                else:
+                    mean, logvar = stats[key]
+                means[idx], logvars[idx] = mean, logvar
+            out[label] = DiagonalGaussianDistribution(torch.cat((means.unsqueeze(1), logvars.unsqueeze(1)), dim=1))
+        return out
+
+    @staticmethod
+    def _masked_mean(values, mask_bg):
+        # sum / sum(mask) if sum(mask) > 0 else 0 -- evaluated on the device: the reference's host-side `if` would
+        # stall the queue once per term (7 syncs per loss evaluation); values and gradients are identical
+        denom = torch.sum(mask_bg)
+        return torch.sum(values) / torch.clamp(denom, min=1) * (denom > 0)
+
+    # ---- pose-head terms (contperceptual.py:111-132,176-212) ------------------------------------------------
+    def compute_pose_loss(self, pred, gt, mask_bg):
+        assert pred.shape == gt.shape, "Prediction and ground truth shapes do not match."
+        assert pred.shape[1] == POSE_6D_DIM, "Invalid pose dimensionality."
+        t1, t2, t3 = (self.pose_loss(pred[:, i], gt[:, i]) for i in range(3))
+        if self.train_on_yaw:
+            v3 = self.rot_loss_fn(torch.sin(pred[:, 3]), torch.sin(gt[:, 3]))
+        else:
+            v3 = self.pose_loss(pred[:, 3], gt[:, 3])
+        pose_loss = self._masked_mean((t1 + t2 + t3 + v3) * mask_bg, mask_bg)
+        return pose_loss, self.pose_weight * pose_loss, t1, t2, t3, v3
+
+    def compute_class_loss(self, class_gt, class_probs, eps=1e-8):
+        class_loss = self.class_loss_fn(class_probs, class_gt)
+        return class_loss, self.class_weight * class_loss
+
+    def compute_bbox_loss(self, bbox_gt, bbox_pred, mask_bg):
+        bbox_loss = self._masked_mean(self.bbox_loss_fn(bbox_gt, bbox_pred) * mask_bg.unsqueeze(1), mask_bg)
+        return bbox_loss, self.bbox_weight * bbox_loss
+
+    def compute_fill_factor_loss(self, fill_factor_gt, fill_factor_pred, mask_bg):
+        loss = self._masked_mean(self.fill_factor_loss_fn(fill_factor_gt, fill_factor_pred) * mask_bg, mask_bg)
+        return loss, self.fill_factor_weight * loss
+
+    def get_mask_loss(self, mask1, mask2, mask_bg):
+        if self.use_mask_loss:
+            mask_loss = self.mask_loss(mask1, mask2)
+            return mask_loss, self.mask_weight * mask_loss
+        return torch.tensor(0.0), torch.tensor(0.0)
+
+    def compute_pose_kl_loss(self, bbox_posterior, mask_bg, class_gt):
+        mean, logvar = bbox_posterior.mean, bbox_posterior.logvar
+        kl = torch.zeros(len(class_gt), mean.size(1), device=mean.device)
+        for idx, label in enumerate(class_gt):  # host loop over the batch, as in the reference (:196-203)
+            if label == "background":
+                continue
+            cur = DiagonalGaussianDistribution(torch.cat((mean[idx].unsqueeze(1), logvar[idx].unsqueeze(1)), dim=1))
+            kl[idx] = cur.kl(self.bbox_distribution_dict[label])
+        return self._masked_mean(kl, mask_bg)
+
+    # ---- reconstruction / KL terms on the image (contperceptual.py:134-164) ----------------------------------
+    def _rec_sums(self, inputs_rgb, recon_rgb, mask_2d_bbox, use_pixel_loss):
+        """Per-sample sum over (c,h,w) of rec_loss = |x*m - xr*m| (+ perceptual_weight * p_loss), and p_loss."""
+        n, c, h, w = inputs_rgb.shape
+        chw = float(c * h * w)
+        if use_pixel_loss:
+            s = ops.l1_masked_sum(inputs_rgb, recon_rgb, mask_2d_bbox)
+        else:
+            s = torch.zeros(n, device=inputs_rgb.device)
+        p_loss = None
+        if self.perceptual_weight > 0:
+            p_loss = self.perceptual_loss(ops.mul_mask(inputs_rgb, mask_2d_bbox), ops.mul_mask(recon_rgb, mask_2d_bbox))
+            s = s + self.perceptual_weight * p_loss.reshape(n) * chw
+        return s, chw
+
+    def _get_nll_loss(self, rec_sums, chw, mask_bg, weights=None):
+        eps = 1e-8
+        nll_sums = rec_sums / (torch.exp(self.logvar) + eps) + self.logvar * chw
+        nll_loss = self._masked_mean(nll_sums * mask_bg, mask_bg)
+        weighted = nll_loss if weights is None else self._masked_mean(weights * nll_sums * mask_bg, mask_bg)
+        return nll_loss, weighted
+
+    def _get_kl_loss(self, posteriors, mask_bg):
+        return self._masked_mean(posteriors.kl() * mask_bg, mask_bg)
+
+    # ---- forward (contperceptual.py:214-375) -------------------------------------------------------------------
+    def forward(self, rgb_gt, mask_gt, pose_gt, dec_obj, dec_pose, class_gt, class_gt_label, bbox_gt, fill_factor_gt,
+                posterior_obj, bbox_posterior, optimizer_idx, global_step, mask_2d_bbox, last_layer=None, cond=None,
+                split="train", weights=None):
+        if mask_2d_bbox is not None:
+            mask_2d_bbox = mask_2d_bbox.to(rgb_gt.device)
+        use_pixel_loss = global_step >= (self.encoder_pretrain_steps + self.pose_conditioned_generation_steps)
+        class_gt = class_gt.to(rgb_gt.device)
+        mask_bg = torch.zeros_like(class_gt, device=rgb_gt.device)
+        mask_bg[class_gt != BACKGROUND_CLASS_IDX] = 1
+        if mask_gt is not None:
+            raise NotImplementedError("image_mask_key is None in the OD-VAE configs; alpha-mask inputs are not on the HIP path")
+        self.use_mask_loss = False  # (:232,248) no mask channel on either side
+        reconstructions = dec_obj
+        recon_rgb = reconstructions[:, :3, :, :] if reconstructions.shape[1] != 3 else reconstructions
+
+        pose_rec = dec_pose[:, :POSE_6D_DIM]
+        lhw_rec = dec_pose[:, POSE_6D_DIM:POSE_6D_DIM + LHW_DIM]
+        fill_factor_rec = dec_pose[:, POSE_6D_DIM + LHW_DIM:BBOX_DIM]
+        class_probs = dec_pose[:, BBOX_DIM:]
+        class_loss, weighted_class_loss = self.compute_class_loss(class_gt, class_probs)
+        bbox_loss, weighted_bbox_loss = self.compute_bbox_loss(bbox_gt, lhw_rec, mask_bg)
+        # QUIRK (:269): (gt, pred) are passed into the (pred, gt) slots; symmetric for l1/l2
+        pose_loss, weighted_pose_loss, t1_loss, t2_loss, t3_loss, v3_loss = self.compute_pose_loss(pose_gt, pose_rec, mask_bg)
+        mask_loss, weighted_mask_loss = self.get_mask_loss(None, None, mask_bg)
+        fill_factor_loss, weighted_fill_factor_loss = self.compute_fill_factor_loss(fill_factor_gt, fill_factor_rec.squeeze(), mask_bg)
+
+        rec_sums, chw = self._rec_sums(rgb_gt, recon_rgb, mask_2d_bbox, use_pixel_loss)
+        nll_loss, weighted_nll_loss = self._get_nll_loss(rec_sums, chw, mask_bg, weights)
+        rec_mean = rec_sums.detach().sum() / (rec_sums.numel() * chw)
+        kl_loss_obj = self._get_kl_loss(posterior_obj, mask_bg)
+        kl_loss_obj_bbox = self.compute_pose_kl_loss(bbox_posterior, mask_bg, class_gt_label)
+        bg4 = mask_bg.reshape(-1, 1, 1, 1)
+
+        if optimizer_idx == 0:
+            assert cond is None and not self.disc_conditional
+            if self.disc_factor > 0.0:
+                logits_fake = self.discriminator(ops.mul_mask(reconstructions, mask_2d_bbox))
+                g_loss = -torch.mean(logits_fake * bg4)
+            else:
+                # discriminator off: its term is multiplied by an exact 0 in the reference, so it is not evaluated
+                # here (the logged g_loss is 0 instead of -mean D(x_rec); losses and gradients are identical)
+                g_loss = torch.zeros((), device=rgb_gt.device)
+            if self.disc_factor > 0.0 and global_step > self.encoder_pretrain_steps:
+                try:
+                    d_weight = self.calculate_adaptive_weight(nll_loss, g_loss, last_layer=last_layer)
+                except RuntimeError:
+                    assert not self.training
+                    d_weight = torch.tensor(0.0)
+            else:
+                d_weight = torch.tensor(0.0)
+            disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_iter_start)
+
+            pose_only = (weighted_pose_loss + weighted_class_loss + weighted_bbox_loss + weighted_fill_factor_loss
+                         + self.kl_weight_bbox * kl_loss_obj_bbox)
+            if self.encoder_pretrain_steps != -1 and global_step > self.encoder_pretrain_steps:
+                loss = (weighted_pose_loss + weighted_mask_loss.to(rgb_gt.device) + weighted_nll_loss + weighted_class_loss
+                        + weighted_bbox_loss + weighted_fill_factor_loss + self.kl_weight_obj * kl_loss_obj
+                        + self.kl_weight_bbox * kl_loss_obj_bbox + d_weight.to(rgb_gt.device) * disc_factor * g_loss)
+            else:
+                loss = pose_only
+
+            log = {
+                "{}/total_loss".format(split): loss.clone().detach().mean(),
+                "{}/logvar".format(split): self.logvar.detach(),
+                "{}/kl_loss_obj".format(split): kl_loss_obj.detach().mean(),
+                "{}/nll_loss".format(split): nll_loss.detach().mean(),
+                "{}/weighted_nll_loss".format(split): weighted_nll_loss.detach().mean(),
+                "{}/rec_loss".format(split): rec_mean,
+                "{}/d_weight".format(split): d_weight.detach(),
+                "{}/disc_factor".format(split): torch.tensor(disc_factor),
+                "{}/g_loss".format(split): g_loss.detach().mean(),
+                "{}/pose_loss".format(split): pose_loss.detach().mean(),
+                "{}/weighted_pose_loss".format(split): weighted_pose_loss.detach().mean(),
+                "{}/mask_loss".format(split): mask_loss.detach().mean(),
+                "{}/weighted_mask_loss".format(split): weighted_mask_loss.detach().mean(),
+                "{}/class_loss".format(split): class_loss.detach(),
+                "{}/weighted_class_loss".format(split): weighted_class_loss.detach(),
+                "{}/bbox_loss".format(split): bbox_loss.detach(),
+                "{}/weighted_bbox_loss".format(split): weighted_bbox_loss.detach(),
+                "{}/t1_loss".format(split): t1_loss.detach().mean(),
+                "{}/t2_loss".format(split): t2_loss.detach().mean(),
+                "{}/t3_loss".format(split): t3_loss.detach().mean(),
+                "{}/v3_loss".format(split): v3_loss.detach().mean(),
+                "{}/kl_loss_bbox".format(split): kl_loss_obj_bbox.detach().mean(),
+                "{}/weighted_kl_loss_bbox".format(split): self.kl_weight_bbox * kl_loss_obj_bbox.detach().mean(),
+                "{}/weighted_kl_loss_obj".format(split): self.kl_weight_obj * kl_loss_obj.detach().mean(),
+                "{}/fill_factor_loss".format(split): fill_factor_loss.detach().mean(),
+                "{}/weighted_fill_factor_loss".format(split): weighted_fill_factor_loss.detach().mean(),
+            }
+            return loss, log
+
+        if optimizer_idx == 1:
+            assert cond is None
+            logits_real = self.discriminator(ops.mul_mask(rgb_gt, mask_2d_bbox).detach())
+            logits_fake = self.discriminator(ops.mul_mask(reconstructions, mask_2d_bbox).detach())
+            disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_iter_start)
+            logits_real = logits_real * bg4
+            logits_fake = logits_fake * bg4
+            d_loss = disc_factor * self.disc_loss(logits_real, logits_fake)
+            log = {"{}/disc_loss".format(split): d_loss.clone().detach().mean(),
+                   "{}/logits_real".format(split): logits_real.detach().mean(),
+                   "{}/logits_fake".format(split): logits_fake.detach().mean()}
+            return d_loss, log

@@ -41,6 +41,48 @@ def _ws(nbytes, like):
     return _lib.workspace.get(nbytes, like.device)
 
 
+class _KernelEvents:
+    """HIP-event brackets around individual kernel launches on torch's current stream (bench.py's live roofline).
+    Off by default; when on, every launch of a tagged kernel records (algorithmic flops, start, stop)."""
+
+    def __init__(self):
+        self.on = False
+        self.rec = {}
+
+    def enable(self):
+        self.on, self.rec = True, {}
+
+    def disable(self):
+        self.on = False
+
+    def begin(self):
+        if not self.on:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, name, flops, ev0):
+        if ev0 is None:
+            return
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        self.rec.setdefault(name, []).append((flops, ev0, ev1))
+
+    def summary(self, name):
+        torch.cuda.synchronize()
+        items = self.rec.get(name, [])
+        if not items:
+            return None
+        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in items)
+        flops = sum(f for f, _, _ in items)
+        return {"launches": len(items), "total_ms": total_ms, "avg_ms": total_ms / len(items),
+                "gflop_per_launch": flops / len(items) / 1e9, "tflops": flops / total_ms / 1e9}
+
+
+KERNEL_EVENTS = _KernelEvents()
+
+
 # ------------------------------------------------------------------------------------------------------
 # 3x3 convolution family
 # ------------------------------------------------------------------------------------------------------
@@ -70,9 +112,11 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual):
     else:
         ho, wo = 2 * hi, 2 * wi
     y = _new_cl(n, cout, ho, wo, x)
+    tag = KERNEL_EVENTS.begin() if (mode == 0 and cout > 32) else None
     _lib.check(L.odvae_conv3x3_f32(mode, x.data_ptr(), n, hi, wi, cin, pack.data_ptr(), cout,
                                    _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, _lib.stream_ptr()),
                "conv3x3(mode=%d)" % mode)
+    KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * ho * wo, tag)
     return y
 
 
@@ -416,3 +460,66 @@ def nhwc_to_nchw(x):
     y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
     _lib.check(L.odvae_nhwc_to_nchw_f32(x.data_ptr(), y.data_ptr(), n, c, h * w, _lib.stream_ptr()), "nhwc_to_nchw")
     return y
+
+
+class _MulMask(Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        L = _L()
+        x = _cl(x)
+        n, c, h, w = x.shape
+        m = mask.detach().to(x.device).float().reshape(n, h * w).contiguous()
+        y = _new_cl(n, c, h, w, x)
+        _lib.check(L.odvae_mul_mask_f32(x.data_ptr(), m.data_ptr(), y.data_ptr(), n * h * w, c, _lib.stream_ptr()), "mul_mask")
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        (m,) = ctx.saved_tensors
+        dy = _cl(dy)
+        n, c, h, w = dy.shape
+        dx = _new_cl(n, c, h, w, dy)
+        _lib.check(L.odvae_mul_mask_f32(dy.data_ptr(), m.data_ptr(), dx.data_ptr(), n * h * w, c, _lib.stream_ptr()), "mul_mask bwd")
+        return dx, None
+
+
+def mul_mask(x, mask):
+    """x * mask_2d_bbox ([B,1,H,W]); identity when mask is None."""
+    return x if mask is None else _MulMask.apply(x, mask)
+
+
+class _LatentCombine(Function):
+    """z * mask + add on the latent (dropout keep-mask already scaled by 1/(1-p); noise or enc_pose as `add`)."""
+
+    @staticmethod
+    def forward(ctx, z, mask, add):
+        L = _L()
+        z = _cl(z)
+        m = _cl(mask) if mask is not None else None
+        a = _cl(add) if add is not None else None
+        n, c, h, w = z.shape
+        out = _new_cl(n, c, h, w, z)
+        _lib.check(L.odvae_latent_combine_f32(z.data_ptr(), _lib.ptr(m), _lib.ptr(a), out.data_ptr(), z.numel(),
+                                              _lib.stream_ptr()), "latent_combine")
+        ctx.save_for_backward(m)
+        ctx.has_add = add is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _L()
+        (m,) = ctx.saved_tensors
+        dout = _cl(dout)
+        dz = dout
+        if m is not None and ctx.needs_input_grad[0]:
+            n, c, h, w = dout.shape
+            dz = _new_cl(n, c, h, w, dout)
+            _lib.check(L.odvae_latent_combine_f32(dout.data_ptr(), m.data_ptr(), None, dz.data_ptr(), dout.numel(),
+                                                  _lib.stream_ptr()), "latent_combine bwd")
+        return dz, None, (dout if ctx.has_add and ctx.needs_input_grad[2] else None)
+
+
+def latent_combine(z, mask=None, add=None):
+    return _LatentCombine.apply(z, mask, add)

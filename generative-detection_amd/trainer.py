@@ -1,0 +1,95 @@
+"""Minimal training loop with the semantics of the reference's PL-1.9 Trainer for this model.
+
+Per batch, for optimizer_idx in (0, 1): toggle_optimizer -> training_step -> zero_grad -> backward (DDP buckets fire)
+-> clip_grad_norm_(gradient_clip_val) -> optimizer.step -> untoggle; global_step advances once per optimizer step,
+i.e. by 2 per batch (every `global_step` threshold in the model and the loss depends on that).
+Launcher concerns of train.py (loggers, checkpoints callbacks, CLI) are out of scope; `fit` takes any iterable of
+batch dicts.
+"""
+import torch
+
+from .parallel import GradReducer
+
+
+class _TrainerHandle:
+    """What `model.trainer` exposes to the module (the optimizer list drives PL-style toggling)."""
+
+    def __init__(self, optimizers):
+        self.optimizers = optimizers
+
+
+class Trainer:
+    def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=32.0):
+        """optimizer_indices: which of the model's optimizers run each batch; (0,) is the "rec+KL only" benchmark
+        configuration (discriminator off, optimizer 1 skipped -- SURVEY.md 8(d))."""
+        self.model = model
+        self.clip = gradient_clip_val
+        self.optimizer_indices = tuple(optimizer_indices)
+        opts, _ = model.configure_optimizers()
+        self.optimizers = opts
+        for o in opts:
+            if hasattr(o, "materialize"):
+                o.materialize()
+        model.trainer = _TrainerHandle(opts)
+        self.reducers = None
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                         and torch.distributed.get_world_size() > 1):
+            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb) for o in opts]
+            self.reducers[0].broadcast_parameters(model)
+
+    # PL-1.9 toggle_optimizer: parameters owned by the *other* optimizers stop requiring grad; parameters in no
+    # optimizer (loss.logvar, the frozen LPIPS net) are left alone
+    def _toggle(self, idx):
+        mine = {id(p) for g in self.optimizers[idx].param_groups for p in g["params"]}
+        saved = {}
+        for j, opt in enumerate(self.optimizers):
+            if j == idx:
+                continue
+            for g in opt.param_groups:
+                for p in g["params"]:
+                    if id(p) not in mine and id(p) not in saved:
+                        saved[id(p)] = (p, p.requires_grad)
+                        p.requires_grad = False
+        return saved
+
+    @staticmethod
+    def _untoggle(saved):
+        for p, rg in saved.values():
+            p.requires_grad = rg
+
+    def training_batch(self, batch, batch_idx=0):
+        """One batch = one step of each scheduled optimizer.  Returns the list of loss tensors (device, not synced)."""
+        model = self.model
+        losses = []
+        for idx in self.optimizer_indices:
+            opt = self.optimizers[idx]
+            saved = self._toggle(idx)
+            try:
+                loss = model.training_step(batch, batch_idx, idx)
+                opt.zero_grad()
+                red = self.reducers[idx] if self.reducers else None
+                if red is not None:
+                    red.prepare_for_backward()
+                loss.backward()
+                if red is not None:
+                    red.finish()
+                if self.clip:
+                    if hasattr(opt, "clip_grad_norm_"):
+                        opt.clip_grad_norm_(self.clip)
+                    else:
+                        torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], self.clip)
+                opt.step()
+            finally:
+                self._untoggle(saved)
+            model._global_step += 1
+            losses.append(loss.detach())
+        return losses
+
+    def fit(self, batches, max_batches=None):
+        self.model.train()
+        out = []
+        for i, batch in enumerate(batches):
+            if max_batches is not None and i >= max_batches:
+                break
+            out.append(self.training_batch(batch, i))
+        return out

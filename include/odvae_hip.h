@@ -113,6 +113,10 @@ int odvae_grad_norm_f32(const float* g, int64_t n, float max_norm, float* out, v
 int odvae_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                         float eps, int step, const float* clip, void* stream);
 int odvae_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, void* stream);
+/* y = x * mask[n][hw] broadcast over channels (inputs*mask_2d_bbox, contperceptual.py:252-255); x,y [npix][C] */
+int odvae_mul_mask_f32(const float* x, const float* mask, float* y, int64_t npix, int C, void* stream);
+/* out = z*mask + add, mask/add may be NULL (dropout on z_obj, +noise, +enc_pose: src/models/autoencoder.py:233-253) */
+int odvae_latent_combine_f32(const float* z, const float* mask, const float* add, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }
