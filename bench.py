@@ -36,19 +36,32 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may actually use: cgroup quota, else affinity mask, capped at the one-GPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(res, batch=1, steps=1):
     """Oracle (plain torch on the host cores) on a bounded sample of the same workload: same yaml, same step
     definition (fwd + bwd + clip + Adam), rec+KL only, at `res` x `res`, batch `batch`."""
     from odvae_amd import synthetic
     from oracle.autoencoder import PoseAutoencoder as OraclePA, train_batch
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     lat = res // 16
     mcfg, _ = synthetic.model_config(YAML, latent_hw=lat)
     p = mcfg.params.to_container()
     torch.manual_seed(23)
     ref = OraclePA(p["ddconfig"], dict(p["lossconfig"]["params"]), p["embed_dim"], p["pose_decoder_config"]["params"],
-                   p["pose_encoder_config"]["params"], feat_dims=p["feat_dims"], dropout_prob_init=p["dropout_prob_init"],
+                   p["pose_encoder_config"]["params"], feat_dims=p.get("feat_dims", [16, 16, 16]),
+                   dropout_prob_init=p["dropout_prob_init"],
                    dropout_prob_final=p["dropout_prob_final"], dropout_warmup_steps=p["dropout_warmup_steps"],
                    pose_conditioned_generation_steps=p["pose_conditioned_generation_steps"])
     ref.learning_rate = 12 * 4.5e-6
@@ -134,6 +147,7 @@ def main():
                                "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
                                "algorithmic_gflop_per_launch": roof["gflop_per_launch"],
                                "share_of_step_time": roof["total_ms"] / (ms * args.steps)}
+        print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res)
         print(json.dumps(out), flush=True)

@@ -53,7 +53,8 @@ class DiagonalGaussianDistribution(object):
         tests inject it (bit-level RNG parity with a CPU draw is otherwise impossible)."""
         shape = (self.parameters.shape[0], self.parameters.shape[1] // 2) + tuple(self.parameters.shape[2:])
         if eps is None:
-            eps = torch.randn(shape).to(device=self.parameters.device)
+            eps = torch.randn(shape)
+        eps = eps.to(device=self.parameters.device)
         if self.deterministic:
             return self.mean + 0.0 * eps
         if self._hip:
