@@ -15,6 +15,7 @@
 // ring (loads for tap t+1 are issued into registers before tap t's MFMAs, written after them).
 // A and B fragments are ds_read_b128: four k-steps per read, k order (8g + 4*half + j) on both.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,6 +29,7 @@ struct ConvParams {
   float* y;               // [N][Ho][Wo][Cout]
   int N, Hi, Wi, Cin, Ho, Wo, Cout, CinP, CoutP;
   int tiles_x, tiles_y;
+  int act;                // 0 none, 1 ReLU (VGG slices of the LPIPS-style net)
 };
 
 template <int MODE> struct Halo;
@@ -209,6 +211,170 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
           const int64_t o = ((int64_t)oy * p.Wo + ox) * p.Cout + co;
           float v = acc[mt][nt][r] + bv;
           if (rn) v += rn[o];
+          if (p.act) v = fmaxf(v, 0.f);
+          yn[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- v2 main loop ------------------------------------------------------------------------------------
+// Same tiling and epilogue, different feeding: weight fragments go global/L2 -> registers directly (the pack
+// layout makes one coalesced 16-byte load per lane a whole B fragment for four k-steps; prefetched one k-group
+// = 16 MFMAs ahead), so LDS holds only the input halo, double-buffered per KC-channel chunk.  One
+// __syncthreads() per chunk (9*KC/8*16 = 576 MFMAs per wave at KC = 32) instead of one per tap (32 MFMAs):
+// rocprof PMC on v1 showed 39 % of wave cycles parked at the per-tap barrier / waitcnt with 3 blocks per CU.
+template <int MODE, int KC, int WMT, int WNT, int WAVES_M, int WAVES_N, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4 && WAVES_M * WMT == 4, "tile layout");
+  constexpr int BN = WAVES_N * WNT * 32;
+  constexpr int HS = KC + 4;
+  constexpr int HPIX = Halo<MODE>::H * Halo<MODE>::W;
+  constexpr int QC = KC / 4;
+  constexpr int NG = KC / 8;
+  constexpr int HALO_F4 = HPIX * QC;
+  constexpr int HALO_IT = (HALO_F4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * HPIX * HS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, h = lane >> 5;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN;
+  int iy0, ix0;
+  halo_origin<MODE>(oy0, ox0, iy0, ix0);
+  const float* xn = p.x + (int64_t)n * p.Hi * p.Wi * p.Cin;
+  const bool vec = (p.Cin & 3) == 0;
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int a = 0; a < WMT; ++a)
+#pragma unroll
+    for (int b = 0; b < WNT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 hreg[HALO_IT];
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < HALO_F4) {
+        const int hp = f / QC, q = f % QC;
+        const int iy = iy0 + hp / Halo<MODE>::W, ix = ix0 + hp % Halo<MODE>::W;
+        const int c = c0 + 4 * q;
+        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin) {
+          const float* src = xn + ((int64_t)iy * p.Wi + ix) * p.Cin + c;
+          if (vec) v = *reinterpret_cast<const float4*>(src);
+          else {
+            v.x = src[0];
+            if (c + 1 < p.Cin) v.y = src[1];
+            if (c + 2 < p.Cin) v.z = src[2];
+            if (c + 3 < p.Cin) v.w = src[3];
+          }
+        }
+      }
+      hreg[i] = v;
+    }
+  };
+  auto store_halo = [&](float* Hs) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      if (f < HALO_F4) *reinterpret_cast<float4*>(Hs + (f / QC) * HS + 4 * (f % QC)) = hreg[i];
+    }
+  };
+
+  // weight fragments: float4 index ((tap * QT + quad) * CoutP + cout)
+  const float4* wq = reinterpret_cast<const float4*>(p.wpk);
+  const int QT = p.CinP / 4;
+  int ncol[WNT];
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt) ncol[nt] = n0 + (wn * WNT + nt) * 32 + li;
+  auto load_b = [&](int ch, int tap, int g, float4 (&b)[WNT]) {
+    const int64_t base = ((int64_t)tap * QT + ch * QC + 2 * g + h) * p.CoutP;
+#pragma unroll
+    for (int nt = 0; nt < WNT; ++nt) b[nt] = wq[base + ncol[nt]];
+  };
+
+  const int nchunks = p.CinP / KC;
+  constexpr int NIT = 9 * NG;   // (tap, k-group) steps per chunk, 16 MFMAs per wave each
+  float4 bc[WNT], bn[WNT], ac[WMT], an[WMT];
+  // A fragment of step `it` of the current chunk: halo pixel of (tile pixel, tap), channels 8g + 4h .. +3
+  auto load_a = [&](const float* Hs, int it, float4 (&a)[WMT]) {
+    const int tap = it / NG, g = it % NG;
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt) {
+      const int pm = (wm * WMT + mt) * 32 + li;
+      bool ok;
+      const int off = halo_index<MODE>(pm / TW, pm % TW, tap / 3, tap % 3, ok) * HS + 4 * h + 8 * g;
+      a[mt] = *reinterpret_cast<const float4*>(Hs + off);
+      if (MODE == 3 && !ok) a[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_halo(0);
+  load_b(0, 0, 0, bc);
+  store_halo(smem);
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* Hs = smem + (ch & 1) * HPIX * HS;
+    const bool more = ch + 1 < nchunks;
+    if (more) load_halo((ch + 1) * KC);
+    load_a(Hs, 0, ac);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      // software pipeline, pinned: operands of step it+1 are requested before step it's MFMAs are issued
+      if (it + 1 < NIT) {
+        load_b(ch, (it + 1) / NG, (it + 1) % NG, bn);
+        load_a(Hs, it + 1, an);
+      } else if (more) {
+        load_b(ch + 1, 0, 0, bn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WNT; ++nt) {
+          acc[mt][nt] = mfma32(ac[mt].x, bc[nt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma32(ac[mt].y, bc[nt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma32(ac[mt].z, bc[nt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma32(ac[mt].w, bc[nt].w, acc[mt][nt]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < WNT; ++nt) bc[nt] = bn[nt];
+#pragma unroll
+      for (int mt = 0; mt < WMT; ++mt) ac[mt] = an[mt];
+    }
+    if (more) store_halo(smem + ((ch + 1) & 1) * HPIX * HS);
+    __syncthreads();
+  }
+
+  float* yn = p.y + (int64_t)n * p.Ho * p.Wo * p.Cout;
+  const float* rn = p.residual ? p.residual + (int64_t)n * p.Ho * p.Wo * p.Cout : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt) {
+    const int co = n0 + (wn * WNT + nt) * 32 + li;
+    if (co >= p.Cout) continue;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
+        const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
+        if (oy < p.Ho && ox < p.Wo) {
+          const int64_t o = ((int64_t)oy * p.Wo + ox) * p.Cout + co;
+          float v = acc[mt][nt][r] + bv;
+          if (rn) v += rn[o];
+          if (p.act) v = fmaxf(v, 0.f);
           yn[o] = v;
         }
       }
@@ -251,7 +417,7 @@ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 extern "C" {
 
 // padded reduction / output channel counts of a weight pack (reduce = channels summed over)
-int odvae_conv3x3_pack_reduce_pad(int c_reduce) { return round_up(c_reduce, 16); }
+int odvae_conv3x3_pack_reduce_pad(int c_reduce) { return round_up(c_reduce, 32); }
 int odvae_conv3x3_pack_out_pad(int c_out) { return c_out <= 32 ? 32 : round_up(c_out, 128); }
 
 // floats in a pack whose reduction axis has c_reduce channels and output axis c_out channels
@@ -274,13 +440,13 @@ int odvae_conv3x3_pack_f32(const float* w, int Cout, int Cin, float* fwd_pack, f
   return ODVAE_OK;
 }
 
-// y = conv3x3(x) (+bias) (+residual).  mode: 0 stride 1 pad 1 | 1 pad(0,1,0,1)+stride 2 |
+// y = act(conv3x3(x) (+bias) (+residual)), act: 0 none | 1 ReLU.  mode: 0 stride 1 pad 1 | 1 pad(0,1,0,1)+stride 2 |
 // 2 nearest-2x-upsample then stride 1 pad 1 | 3 transposed stride 2 (data gradient of mode 1).
 // wpk: pack with reduction axis Cin and output axis Cout (for data gradients pass the dgrad pack,
 // Cin = channels of x (= dy), Cout = channels of y (= dx)).
 int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
                       const float* wpk, int Cout, const float* bias, const float* residual,
-                      float* y, int Ho, int Wo, void* stream) {
+                      float* y, int Ho, int Wo, int act, void* stream) {
   ODVAE_CHECK_ARG(x && wpk && y, "conv3x3: null operand");
   ODVAE_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv3x3: empty shape");
   ODVAE_CHECK_ARG(mode >= 0 && mode <= 3, "conv3x3: mode %d", mode);
@@ -294,19 +460,36 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.CinP = odvae_conv3x3_pack_reduce_pad(Cin); p.CoutP = odvae_conv3x3_pack_out_pad(Cout);
   p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, TH);
+  p.act = act;
   const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool narrow = Cout <= 32;
   dim3 block(256);
-#define ODVAE_CONV_LAUNCH(MODE, KC)                                                                      \
-  if (narrow) hipLaunchKernelGGL((conv3x3_kernel<MODE, KC, 1, 1, 4, 1>), dim3((unsigned)sp, p.CoutP / 32), block, 0, st, p); \
-  else hipLaunchKernelGGL((conv3x3_kernel<MODE, KC, 2, 2, 2, 2>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p)
-  switch (mode) {
-    case 0: ODVAE_CONV_LAUNCH(0, 16); break;
-    case 1: ODVAE_CONV_LAUNCH(1, 8); break;
-    case 2: ODVAE_CONV_LAUNCH(2, 16); break;
-    default: ODVAE_CONV_LAUNCH(3, 16); break;
+  // ODVAE_CONV_V1=1 selects the round-1 per-tap-barrier kernel (kept for in-process A/B timing)
+  static const int variant = getenv("ODVAE_CONV_VARIANT") ? atoi(getenv("ODVAE_CONV_VARIANT")) : 1;
+  const bool use_v1 = variant == 0;
+#define ODVAE_CONV_LAUNCH(KERNEL, MODE, KC)                                                                      \
+  if (narrow) hipLaunchKernelGGL((KERNEL<MODE, KC, 1, 1, 4, 1>), dim3((unsigned)sp, p.CoutP / 32), block, 0, st, p); \
+  else hipLaunchKernelGGL((KERNEL<MODE, KC, 2, 2, 2, 2>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p)
+  if (use_v1) {
+    switch (mode) {
+      case 0: ODVAE_CONV_LAUNCH(conv3x3_kernel, 0, 16); break;
+      case 1: ODVAE_CONV_LAUNCH(conv3x3_kernel, 1, 8); break;
+      case 2: ODVAE_CONV_LAUNCH(conv3x3_kernel, 2, 16); break;
+      default: ODVAE_CONV_LAUNCH(conv3x3_kernel, 3, 16); break;
+    }
+  } else {
+    switch (mode) {
+      case 0:
+        if (variant == 3 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 16, 2, 2, 2, 2, 3>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
+        else if (variant == 2) { ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 16); }
+        else { ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 32); }
+        break;
+      case 1: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 1, 8); break;
+      case 2: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 2, 32); break;
+      default: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 3, 32); break;
+    }
   }
 #undef ODVAE_CONV_LAUNCH
   ODVAE_LAUNCH_CHECK("conv3x3");

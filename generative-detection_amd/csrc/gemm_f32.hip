@@ -224,7 +224,7 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0,
                   "gemm_f32: lda/ldb/strides must be multiples of 4 floats");
   ODVAE_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_f32: A/B must be 16-byte aligned");
-  ODVAE_CHECK_ARG(K % 4 == 0, "gemm_f32: K=%d must be a multiple of 4", K);
+  if (!transA || transB) ODVAE_CHECK_ARG(K % 4 == 0, "gemm_f32: a k-contiguous operand needs K %% 4 == 0 (K=%d)", K);
   if (transA) ODVAE_CHECK_ARG(M % 4 == 0, "gemm_f32: transA needs M %% 4 == 0 (M=%d)", M);
   if (!transB) ODVAE_CHECK_ARG(N % 4 == 0, "gemm_f32: transB=0 needs N %% 4 == 0 (N=%d)", N);
 

@@ -24,7 +24,7 @@ PROTOTYPES = {
     "odvae_conv3x3_pack_out_pad": (_I, [_I]),
     "odvae_conv3x3_pack_floats": (_Z, [_I, _I]),
     "odvae_conv3x3_pack_f32": (_I, [_P, _I, _I, _P, _P, _P]),
-    "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
@@ -46,6 +46,19 @@ PROTOTYPES = {
     "odvae_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "odvae_mul_mask_f32": (_I, [_P, _P, _P, _L, _I, _P]),
     "odvae_latent_combine_f32": (_I, [_P, _P, _P, _P, _L, _P]),
+    "odvae_im2col4x4_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "odvae_col2im4x4_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "odvae_weight4x4_reorder_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "odvae_batchnorm_workspace_bytes": (_Z, [_L, _I]),
+    "odvae_batchnorm_lrelu_fwd_f32": (_I, [_P, _L, _I, _P, _P, _F, _F, _F, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "odvae_batchnorm_lrelu_bwd_f32": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
+    "odvae_leaky_relu_f32": (_I, [_P, _P, _F, _L, _P]),
+    "odvae_leaky_relu_bwd_f32": (_I, [_P, _P, _P, _F, _L, _P]),
+    "odvae_scaling_layer_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    "odvae_maxpool2x2_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "odvae_maxpool2x2_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "odvae_lpips_distance_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "odvae_lpips_distance_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 

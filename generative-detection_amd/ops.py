@@ -102,7 +102,7 @@ def pack_conv3x3(weight, want_fwd=True, want_dgrad=False):
     return fwd, dgr
 
 
-def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual):
+def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
     L = _L()
     n, _, hi, wi = x.shape
     if mode == 0:
@@ -114,7 +114,7 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual):
     y = _new_cl(n, cout, ho, wo, x)
     tag = KERNEL_EVENTS.begin() if (mode == 0 and cout > 32) else None
     _lib.check(L.odvae_conv3x3_f32(mode, x.data_ptr(), n, hi, wi, cin, pack.data_ptr(), cout,
-                                   _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, _lib.stream_ptr()),
+                                   _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, int(act), _lib.stream_ptr()),
                "conv3x3(mode=%d)" % mode)
     KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * ho * wo, tag)
     return y
@@ -124,25 +124,31 @@ class _Conv3x3(Function):
     """mode 0: stride 1 pad 1; mode 1: Downsample (pad (0,1,0,1), stride 2); mode 2: Upsample (nearest 2x) + conv."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, mode):
+    def forward(ctx, x, weight, bias, residual, mode, relu):
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
         fwd_pack, _ = pack_conv3x3(weight, True, False)
         b = bias.detach().contiguous() if bias is not None else None
-        y = _conv3x3_raw(mode, x, fwd_pack, cin, cout, b, res)
+        y = _conv3x3_raw(mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
         ctx.mode = mode
+        ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _L()
-        x, weight = ctx.saved_tensors
+        x, weight, y_act = ctx.saved_tensors
         mode = ctx.mode
         dy = _cl(dy)
+        if ctx.relu:  # gradient through the fused ReLU: dy * (y > 0)
+            g = _new_cl(*[dy.shape[i] for i in (0, 1, 2, 3)], dy)
+            _lib.check(L.odvae_leaky_relu_bwd_f32(y_act.data_ptr(), dy.data_ptr(), g.data_ptr(), 0.0, dy.numel(),
+                                                  _lib.stream_ptr()), "relu_bwd")
+            dy = g
         cout, cin = weight.shape[0], weight.shape[1]
         n, _, hi, wi = x.shape
         _, _, ho, wo = dy.shape
@@ -167,11 +173,11 @@ class _Conv3x3(Function):
                                                  dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
                        "conv3x3_wgrad(mode=%d)" % mode)
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None
 
 
-def conv3x3(x, weight, bias=None, residual=None, mode=0):
-    return _Conv3x3.apply(x, weight, bias, residual, mode)
+def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False):
+    return _Conv3x3.apply(x, weight, bias, residual, mode, relu)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -523,3 +529,242 @@ class _LatentCombine(Function):
 
 def latent_combine(z, mask=None, add=None):
     return _LatentCombine.apply(z, mask, add)
+
+
+# ------------------------------------------------------------------------------------------------------
+# PatchGAN discriminator pieces (gan_f32.hip)
+# ------------------------------------------------------------------------------------------------------
+def _conv4x4_out(h, stride):
+    return (h + 2 - 4) // stride + 1
+
+
+class _Conv4x4(Function):
+    """Conv2d(k=4, pad=1, stride 1|2) = im2col + MFMA GEMM; weight OIHW [Cout][Cin][4][4]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        L = _L()
+        x = _cl(x)
+        n, cin, hi, wi = x.shape
+        cout = weight.shape[0]
+        ho, wo = _conv4x4_out(hi, stride), _conv4x4_out(wi, stride)
+        m, k = n * ho * wo, 16 * cin
+        st = _lib.stream_ptr()
+        wg = torch.empty(cout, k, dtype=torch.float32, device=x.device)
+        _lib.check(L.odvae_weight4x4_reorder_f32(weight.detach().contiguous().data_ptr(), wg.data_ptr(), cout, cin, 1, st), "weight4x4_reorder")
+        cols = torch.empty(m, k, dtype=torch.float32, device=x.device)
+        _lib.check(L.odvae_im2col4x4_f32(x.data_ptr(), cols.data_ptr(), n, hi, wi, cin, ho, wo, stride, st), "im2col4x4")
+        y = _new_cl(n, cout, ho, wo, x)
+        b = bias.detach().contiguous() if bias is not None else None
+        gemm(0, 1, m, cout, k, 1.0, cols, k, 0, wg, k, 0, y, cout, 0, b)
+        ctx.stride, ctx.has_bias, ctx.xshape = stride, bias is not None, (n, cin, hi, wi)
+        ctx.save_for_backward(cols, wg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        cols, wg = ctx.saved_tensors
+        dy = _cl(dy)
+        n, cin, hi, wi = ctx.xshape
+        _, cout, ho, wo = dy.shape
+        m, k = n * ho * wo, 16 * cin
+        st = _lib.stream_ptr()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dcols = torch.empty(m, k, dtype=torch.float32, device=dy.device)
+            gemm(0, 0, m, k, cout, 1.0, dy, cout, 0, wg, k, 0, dcols, k, 0)
+            dx = _new_cl(n, cin, hi, wi, dy)
+            _lib.check(L.odvae_col2im4x4_f32(dcols.data_ptr(), dx.data_ptr(), n, hi, wi, cin, ho, wo, ctx.stride, st), "col2im4x4")
+        if ctx.needs_input_grad[1]:
+            dwg = torch.empty(cout, k, dtype=torch.float32, device=dy.device)
+            gemm(1, 0, cout, k, m, 1.0, dy, cout, 0, cols, k, 0, dwg, k, 0)
+            dw = torch.empty(cout, cin, 4, 4, dtype=torch.float32, device=dy.device)
+            _lib.check(L.odvae_weight4x4_reorder_f32(dwg.data_ptr(), dw.data_ptr(), cout, cin, 0, st), "weight4x4_reorder")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, m, cout)
+        return dx, dw, db, None
+
+
+def conv4x4(x, weight, bias, stride):
+    """PatchGAN convolution.  Cout = 1 (the logit head) is zero-padded to 4 output channels for the GEMM's
+    float4 staging and sliced back (torch cat/slice on [4,C,4,4] / [B,4,30,30]-sized tensors)."""
+    cout = weight.shape[0]
+    if cout % 4 == 0:
+        return _Conv4x4.apply(x, weight, bias, stride)
+    pad = 4 - cout % 4
+    wp = torch.cat([weight, weight.new_zeros((pad,) + tuple(weight.shape[1:]))], dim=0)
+    bp = torch.cat([bias, bias.new_zeros(pad)]) if bias is not None else None
+    return _Conv4x4.apply(x, wp, bp, stride)[:, :cout]
+
+
+class _BatchNormLReLU(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, slope, train):
+        L = _L()
+        x = _cl(x)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        y = _new_cl(n, c, h, w, x)
+        if train:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        else:  # eval: running estimates (tiny [C] torch ops)
+            mean = running_mean.detach().clone()
+            rstd = torch.rsqrt(running_var.detach() + eps)
+        wp, wn = _ws(L.odvae_batchnorm_workspace_bytes(rows, c), x)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        _lib.check(L.odvae_batchnorm_lrelu_fwd_f32(x.data_ptr(), rows, c, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
+                                                   float(slope), int(train), mean.data_ptr(), rstd.data_ptr(),
+                                                   _lib.ptr(running_mean) if train else None,
+                                                   _lib.ptr(running_var) if train else None, y.data_ptr(), wp, wn,
+                                                   _lib.stream_ptr()), "batchnorm_lrelu_fwd")
+        ctx.slope, ctx.train = float(slope), int(train)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = _cl(dy)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dx = _new_cl(n, c, h, w, x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        wp, wn = _ws(L.odvae_batchnorm_workspace_bytes(rows, c), x)
+        _lib.check(L.odvae_batchnorm_lrelu_bwd_f32(x.data_ptr(), dy.data_ptr(), rows, c, gamma.detach().contiguous().data_ptr(),
+                                                   beta.detach().contiguous().data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   ctx.slope, ctx.train, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), wp, wn,
+                                                   _lib.stream_ptr()), "batchnorm_lrelu_bwd")
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batchnorm_lrelu(x, bn, slope):
+    """BatchNorm2d `bn` (parameter/buffer holder) + LeakyReLU(slope); updates running stats in training mode."""
+    train = bn.training or not bn.track_running_stats
+    if train and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BatchNormLReLU.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, slope, train)
+
+
+class _LeakyReLU(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        L = _L()
+        x = _cl(x)
+        y = _new_cl(*x.shape, x)
+        _lib.check(L.odvae_leaky_relu_f32(x.data_ptr(), y.data_ptr(), float(slope), x.numel(), _lib.stream_ptr()), "leaky_relu")
+        ctx.slope = float(slope)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        (x,) = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = _new_cl(*x.shape, x)
+        _lib.check(L.odvae_leaky_relu_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), ctx.slope, x.numel(), _lib.stream_ptr()),
+                   "leaky_relu_bwd")
+        return dx, None
+
+
+def leaky_relu(x, slope):
+    return _LeakyReLU.apply(x, slope)
+
+
+# ------------------------------------------------------------------------------------------------------
+# LPIPS-style perceptual network pieces (lpips_f32.hip)
+# ------------------------------------------------------------------------------------------------------
+class _ScalingLayer(Function):
+    @staticmethod
+    def forward(ctx, x, shift, scale):
+        L = _L()
+        x = _cl(x)
+        n, c, h, w = x.shape
+        sh, sc = shift.detach().reshape(-1).contiguous(), scale.detach().reshape(-1).contiguous()
+        y = _new_cl(n, c, h, w, x)
+        _lib.check(L.odvae_scaling_layer_f32(x.data_ptr(), sh.data_ptr(), sc.data_ptr(), y.data_ptr(), n * h * w, c, 0,
+                                             _lib.stream_ptr()), "scaling_layer")
+        ctx.save_for_backward(sh, sc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        sh, sc = ctx.saved_tensors
+        dy = _cl(dy)
+        n, c, h, w = dy.shape
+        dx = _new_cl(n, c, h, w, dy)
+        _lib.check(L.odvae_scaling_layer_f32(dy.data_ptr(), sh.data_ptr(), sc.data_ptr(), dx.data_ptr(), n * h * w, c, 1,
+                                             _lib.stream_ptr()), "scaling_layer bwd")
+        return dx, None, None
+
+
+def scale_shift(x, shift, scale):
+    return _ScalingLayer.apply(x, shift, scale)
+
+
+class _MaxPool2x2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = _L()
+        x = _cl(x)
+        n, c, h, w = x.shape
+        y = _new_cl(n, c, h // 2, w // 2, x)
+        _lib.check(L.odvae_maxpool2x2_f32(x.data_ptr(), y.data_ptr(), n, h // 2, w // 2, c, _lib.stream_ptr()), "maxpool2x2")
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        x, y = ctx.saved_tensors
+        dy = _cl(dy)
+        n, c, h, w = x.shape
+        dx = _new_cl(n, c, h, w, x)
+        _lib.check(L.odvae_maxpool2x2_bwd_f32(x.data_ptr(), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, h // 2, w // 2, c,
+                                              _lib.stream_ptr()), "maxpool2x2_bwd")
+        return dx
+
+
+def maxpool2x2(x):
+    return _MaxPool2x2.apply(x)
+
+
+class _LpipsDistance(Function):
+    """[B] spatial mean of lin_w . (normalize(f0) - normalize(f1))^2; differentiable w.r.t. f1 (the reconstruction)."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, lin_w):
+        L = _L()
+        f0, f1 = _cl(f0), _cl(f1)
+        n, c, h, w = f0.shape
+        wv = lin_w.detach().reshape(-1).contiguous()
+        out = torch.empty(n, dtype=torch.float32, device=f0.device)
+        wp, wn = _ws(n * 1024, f0)
+        _lib.check(L.odvae_lpips_distance_f32(f0.data_ptr(), f1.data_ptr(), wv.data_ptr(), out.data_ptr(), n, h * w, c, wp, wn,
+                                              _lib.stream_ptr()), "lpips_distance")
+        ctx.save_for_backward(f0, f1, wv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _L()
+        f0, f1, wv = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("lpips_layer_distance: gradient w.r.t. the first (input) branch is not on the OD-VAE path")
+        n, c, h, w = f1.shape
+        df1 = None
+        if ctx.needs_input_grad[1]:
+            df1 = _new_cl(n, c, h, w, f1)
+            _lib.check(L.odvae_lpips_distance_bwd_f32(f0.data_ptr(), f1.data_ptr(), wv.data_ptr(), g.contiguous().data_ptr(),
+                                                      df1.data_ptr(), n, h * w, c, _lib.stream_ptr()), "lpips_distance_bwd")
+        return None, df1, None
+
+
+def lpips_layer_distance(f0, f1, lin_w):
+    return _LpipsDistance.apply(f0, f1, lin_w)

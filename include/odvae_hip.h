@@ -64,7 +64,7 @@ int odvae_conv3x3_pack_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pa
  * The data gradient of mode 0 is mode 0 with the dgrad pack. */
 int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
                       const float* wpk, int Cout, const float* bias, const float* residual,
-                      float* y, int Ho, int Wo, void* stream);
+                      float* y, int Ho, int Wo, int act /* 0 none, 1 ReLU */, void* stream);
 
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2)
  * dw is OIHW [Cout][Cin][3][3], overwritten; dbias [Cout] or NULL. */
@@ -117,6 +117,37 @@ int odvae_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, void*
 int odvae_mul_mask_f32(const float* x, const float* mask, float* y, int64_t npix, int C, void* stream);
 /* out = z*mask + add, mask/add may be NULL (dropout on z_obj, +noise, +enc_pose: src/models/autoencoder.py:233-253) */
 int odvae_latent_combine_f32(const float* z, const float* mask, const float* add, float* out, int64_t n, void* stream);
+
+/* ---- gan_f32.hip: PatchGAN NLayerDiscriminator ([UPSTREAM] taming discriminator; contperceptual.py:285,355-356) ----
+ * Conv2d(k=4, pad=1, stride 1|2) = im2col + odvae_gemm_f32 against the weight reordered to [Cout][(kh,kw,ci)];
+ * cols is [N*Ho*Wo][16*C]; col2im is its adjoint (data gradient). */
+int odvae_im2col4x4_f32(const float* x, float* cols, int N, int Hi, int Wi, int C, int Ho, int Wo, int stride, void* stream);
+int odvae_col2im4x4_f32(const float* dcols, float* dx, int N, int Hi, int Wi, int C, int Ho, int Wo, int stride, void* stream);
+int odvae_weight4x4_reorder_f32(const float* src, float* dst, int Cout, int Cin, int to_gemm, void* stream);
+/* torch.nn.BatchNorm2d (batch statistics when train=1, running-stat update with momentum) + LeakyReLU(slope), x [rows][C] */
+size_t odvae_batchnorm_workspace_bytes(int64_t rows, int C);
+int odvae_batchnorm_lrelu_fwd_f32(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float slope, int train, float* mean, float* rstd,
+                                  float* running_mean, float* running_var, float* y,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+int odvae_batchnorm_lrelu_bwd_f32(const float* x, const float* dy, int64_t rows, int C, const float* gamma, const float* beta,
+                                  const float* mean, const float* rstd, float slope, int train,
+                                  float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.nn.LeakyReLU(slope); the backward with slope 0 is the ReLU backward */
+int odvae_leaky_relu_f32(const float* x, float* y, float slope, int64_t n, void* stream);
+int odvae_leaky_relu_bwd_f32(const float* x, const float* dy, float* dx, float slope, int64_t n, void* stream);
+
+/* ---- lpips_f32.hip: LPIPS-style perceptual distance ([UPSTREAM] taming lpips.py; contperceptual.py:143) ------------- */
+/* ScalingLayer (x - shift[c]) / scale[c]; backward=1 computes x / scale[c] */
+int odvae_scaling_layer_f32(const float* x, const float* shift, const float* scale, float* y, int64_t npix, int C, int backward, void* stream);
+/* torch.nn.MaxPool2d(2, 2): x [N][2Ho][2Wo][C] -> y [N][Ho][Wo][C] */
+int odvae_maxpool2x2_f32(const float* x, float* y, int N, int Ho, int Wo, int C, void* stream);
+int odvae_maxpool2x2_bwd_f32(const float* x, const float* y, const float* dy, float* dx, int N, int Ho, int Wo, int C, void* stream);
+/* out[n] = spatial mean of lin_w . (normalize_tensor(f0) - normalize_tensor(f1))^2 ; gradient w.r.t. f1 only */
+int odvae_lpips_distance_f32(const float* f0, const float* f1, const float* w, float* out, int N, int HW, int C,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int odvae_lpips_distance_bwd_f32(const float* f0, const float* f1, const float* w, const float* g, float* df1,
+                                 int N, int HW, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ def test_identification_calls(built_lib):
     assert handle.odvae_abi_version() == 1
     assert handle.odvae_target_arch() == b"gfx950"
     # pure host queries (no kernel launch)
-    assert handle.odvae_conv3x3_pack_reduce_pad(3) == 16 and handle.odvae_conv3x3_pack_out_pad(3) == 32
+    assert handle.odvae_conv3x3_pack_reduce_pad(3) == 32 and handle.odvae_conv3x3_pack_out_pad(3) == 32
     assert handle.odvae_conv3x3_pack_out_pad(256) == 256
     assert handle.odvae_conv3x3_pack_floats(128, 128) == 9 * 128 * 128
     assert handle.odvae_gemm_f32_workspace_bytes(128, 128, 1 << 20, 1) > 0

@@ -72,6 +72,41 @@ def test_training_step_matches_oracle(hip_lib):
     assert worst[1] < 5e-3, "param grad %s rel err %.3e" % worst
 
 
+def test_gan_lpips_training_batch_matches_oracle(hip_lib):
+    """BASELINE.json configs[3] in miniature: PatchGAN + LPIPS-style loss, both optimizers (generator step with the
+    adaptive weight from two partial backward passes, then the discriminator step), two batches."""
+    from odvae_amd import synthetic
+    from odvae_amd.trainer import Trainer
+    from oracle.autoencoder import train_batch
+    model, ref = build_pair(perceptual_weight=1.0, disc_factor=1.0)
+    model.train(); ref.train()
+    model.loss.perceptual_loss.eval(); ref.loss.perceptual_loss.eval()
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1))
+    ref_opts = ref.configure_optimizers()
+    for step in range(2):
+        batch = synthetic.make_batch(2, 64, seed=300 + step)
+        noises = {0: synthetic.make_noise(2, 4, dropout_p=0.7, seed=400 + 2 * step),
+                  1: synthetic.make_noise(2, 4, dropout_p=0.7, seed=401 + 2 * step)}
+        got = []
+        for idx in (0, 1):   # one optimizer at a time so each forward sees its own injected noise
+            model.injected_noise = noises[idx]
+            trainer.optimizer_indices = (idx,)
+            got.append(trainer.training_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, step)[0])
+            if idx == 0:
+                logs = dict(model.logged_metrics)
+        out = train_batch(ref, ref_opts, batch, noises, optimizer_indices=(0, 1), clip=1.0)
+        for idx in (0, 1):
+            a, b = got[idx].item(), out[idx][0].item()
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (step, idx, a, b)
+        for key in ("g_loss", "d_weight", "nll_loss", "rec_loss"):
+            assert rel(logs["train/" + key], out[0][1]["train/" + key]) < 5e-3, (step, key, logs["train/" + key], out[0][1]["train/" + key])
+    assert model.global_step == 4 and ref.global_step == 4
+    ref_sd = ref.state_dict()
+    worst = max(rel(v, ref_sd[k]) for k, v in model.state_dict().items()
+                if v.dtype == torch.float32 and k.startswith(("decoder", "loss.discriminator")))
+    assert worst < 5e-3, worst
+
+
 def test_three_step_loss_curve_matches_oracle(hip_lib):
     from odvae_amd import synthetic
     from odvae_amd.trainer import Trainer
