@@ -13,6 +13,7 @@
 // one dy read feeds nine MFMAs.  Blocks write partial slabs; a second kernel sums them in a fixed order
 // (deterministic) and writes OIHW.  db = column sums of dy ride along in the ci-tile-0 blocks.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -157,6 +158,123 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradParams p) {
   }
 }
 
+// ---- v2: LDS-DMA staging, double-buffered -------------------------------------------------------------------
+// Block = 512 threads = 8 waves (2 ci x 4 co sub-tiles of 32x32, all 9 taps each): 64 ci x 128 co per block.
+// The halo patch [HPIX][64 ci] and the dy tile [NPIX][128 co] of the NEXT pixel tile are fetched by
+// buffer_load ... lds (1 KiB per wave-instruction, straight into LDS, no staging registers; out-of-image lanes
+// point past the buffer's num_records and therefore write zeros) while the current tile is multiplied:
+// one barrier per tile, every byte of a tile in flight at once, 2 waves per SIMD.  Needs Cin % 4 == Cout % 4 == 0.
+constexpr int BCI2 = 64, BCO2 = 128;
+
+template <int MODE, int TH>
+struct DmaGeom {
+  static constexpr int HPIX = Halo<MODE, TH>::H * Halo<MODE, TH>::W;
+  static constexpr int NPIX = TH * TW;
+  static constexpr int NH = (HPIX * (BCI2 / 4) + 63) / 64;   // 1 KiB pieces of the halo image
+  static constexpr int ND = NPIX * (BCO2 / 4) / 64;          // 1 KiB pieces of the dy image
+  static constexpr int XS_F = NH * 256;                      // floats (halo image padded to whole pieces)
+  static constexpr int BUF_F = XS_F + NPIX * BCO2;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int MODE, int TH>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_dma_kernel(WgradParams p) {
+  using G = DmaGeom<MODE, TH>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 * BUF_F floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, h = lane >> 5;
+  const int split = blockIdx.x;
+  const int ci_tile = blockIdx.y % p.ci_tiles, co_tile = blockIdx.y / p.ci_tiles;
+  const int ci0 = ci_tile * BCI2, co0 = co_tile * BCO2;
+  const bool do_bias = p.bslab != nullptr && ci_tile == 0 && wm == 0;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  auto issue = [&](int tile, int buf) {
+    int t = tile;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    int iy0, ix0;
+    if (MODE == 0) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
+    else if (MODE == 1) { iy0 = 2 * oy0; ix0 = 2 * ox0; }
+    else { iy0 = oy0 / 2 - 1; ix0 = ox0 / 2 - 1; }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin), 0, p.Hi * p.Wi * p.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy + (int64_t)n * p.Ho * p.Wo * p.Cout), 0, p.Ho * p.Wo * p.Cout * 4, 0x00020000);
+    float* base = smem + buf * G::BUF_F;
+    const unsigned OOB = 0x7FFFFFF0u;   // >= num_records: the load returns 0
+    for (int j = wave; j < G::NH + G::ND; j += 8) {
+      if (j < G::NH) {
+        const int f = j * 64 + lane;
+        const int hp = f >> 4, q = f & 15;
+        const int iy = iy0 + hp / Halo<MODE, TH>::W, ix = ix0 + hp % Halo<MODE, TH>::W;
+        const int c = ci0 + 4 * q;
+        const bool ok = hp < G::HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin;
+        const unsigned voff = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + c) * 4) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + j * 256), 16, voff, 0, 0, 0);
+      } else {
+        const int jj = j - G::NH;
+        const int f = jj * 64 + lane;
+        const int px = f >> 5, q = f & 31;
+        const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+        const int c = co0 + 4 * q;
+        const bool ok = oy < p.Ho && ox < p.Wo && c < p.Cout;
+        const unsigned voff = ok ? (unsigned)(((oy * p.Wo + ox) * p.Cout + c) * 4) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(base + G::XS_F + jj * 256), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  const int t_beg = split * p.tiles_per_split;
+  const int ntl = min(p.ntiles, t_beg + p.tiles_per_split) - t_beg;
+  if (ntl > 0) issue(t_beg, 0);
+  for (int it = 0; it < ntl; ++it) {
+    const int cur = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` have landed
+    __syncthreads();                                    // everyone's have; buffer cur^1 is free again
+    if (it + 1 < ntl) issue(t_beg + it + 1, cur ^ 1);
+    const float* xa = smem + cur * G::BUF_F + wm * 32 + li;            // [HPIX][64]
+    const float* db = smem + cur * G::BUF_F + G::XS_F + wn * 32 + li;  // [NPIX][128]
+#pragma unroll 4
+    for (int s = 0; s < G::NPIX / 2; ++s) {
+      const int px = 2 * s + h;
+      const int r = px / TW, c = px % TW;
+      const float b = db[px * BCO2];
+      if (do_bias) bsum += b;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const float a = xa[halo_index<MODE, TH>(r, c, t9 / 3, t9 % 3) * BCI2];
+        acc[t9] = mfma32(a, b, acc[t9]);
+      }
+    }
+  }
+
+  const int co = co0 + wn * 32 + li;
+  float* sl = p.slab + (int64_t)split * 9 * p.CinP * p.CoutP;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + wm * 32 + acc_row(r, lane);
+      sl[((int64_t)t9 * p.CinP + ci) * p.CoutP + co] = acc[t9][r];
+    }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0) p.bslab[(int64_t)split * p.CoutP + co] = bsum;
+  }
+}
+
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                             int nsplit, int Cin, int Cout, int CinP, int CoutP,
                                             float* __restrict__ dw, float* __restrict__ dbias) {
@@ -184,20 +302,25 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, cons
   }
 }
 
-struct Plan { int th, tiles_x, tiles_y, ntiles, nsplit, tiles_per_split, CinP, CoutP, ci_tiles, co_tiles; };
+struct Plan { int v2, th, tiles_x, tiles_y, ntiles, nsplit, tiles_per_split, CinP, CoutP, ci_tiles, co_tiles; };
 
+// v2 (LDS-DMA) whenever both channel counts allow 16-byte pieces and the 128-wide co tile is not mostly padding;
+// ODVAE_WGRAD_V1=1 forces the register-staged kernel (in-process A/B)
 Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
+  static const bool force_v1 = getenv("ODVAE_WGRAD_V1") != nullptr;
   Plan pl;
-  pl.th = mode == 1 ? 4 : 8;
+  pl.v2 = !force_v1 && Cin % 4 == 0 && Cout % 4 == 0 && Cout > 64;
+  const int bci = pl.v2 ? BCI2 : BC, bco = pl.v2 ? BCO2 : BC;
+  pl.th = pl.v2 ? (mode == 1 ? 2 : 4) : (mode == 1 ? 4 : 8);
   pl.tiles_x = ceil_div(Wo, TW);
   pl.tiles_y = ceil_div(Ho, pl.th);
   pl.ntiles = pl.tiles_x * pl.tiles_y * N;
-  pl.CinP = ceil_div(Cin, BC) * BC;
-  pl.CoutP = ceil_div(Cout, BC) * BC;
-  pl.ci_tiles = pl.CinP / BC;
-  pl.co_tiles = pl.CoutP / BC;
+  pl.CinP = ceil_div(Cin, bci) * bci;
+  pl.CoutP = ceil_div(Cout, bco) * bco;
+  pl.ci_tiles = pl.CinP / bci;
+  pl.co_tiles = pl.CoutP / bco;
   const int ctiles = pl.ci_tiles * pl.co_tiles;
-  int nsplit = ceil_div(1024, ctiles);
+  int nsplit = ceil_div(pl.v2 ? 512 : 1024, ctiles);   // v2 runs one 8-wave block per CU
   if (nsplit > pl.ntiles) nsplit = pl.ntiles;
   if (nsplit < 1) nsplit = 1;
   pl.tiles_per_split = ceil_div(pl.ntiles, nsplit);
@@ -207,6 +330,14 @@ Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
 
 template <int MODE, int TH>
 size_t wgrad_smem_bytes() { return (size_t)(Halo<MODE, TH>::H * Halo<MODE, TH>::W + TH * TW) * BC * sizeof(float); }
+
+template <typename K>
+hipError_t launch_dyn(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t st, const WgradParams& p) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kernel, grid, block, smem, st, p);
+  return hipSuccess;
+}
 
 }  // namespace
 
@@ -228,6 +359,7 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
   if (mode == 1) ODVAE_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv3x3_wgrad mode 1: need even Hi,Wi");
   if (mode == 2) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3_wgrad mode 2: need Ho=2*Hi");
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv3x3_wgrad: x/dy must be 16-byte aligned");
+  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 4 < 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * 4 < 0x7FFFFFF0ll, "conv3x3_wgrad: one image must stay below 2 GiB");
   const Plan pl = make_plan(mode, N, Ho, Wo, Cin, Cout);
   const size_t need = odvae_conv3x3_wgrad_workspace_bytes(mode, N, Ho, Wo, Cin, Cout);
   if (!workspace || workspace_bytes < need) {
@@ -243,20 +375,16 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
   p.tiles_per_split = pl.tiles_per_split; p.ci_tiles = pl.ci_tiles;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(pl.nsplit, pl.ci_tiles * pl.co_tiles), block(256);
+  dim3 grid(pl.nsplit, pl.ci_tiles * pl.co_tiles);
   hipError_t e = hipSuccess;
-  if (mode == 0) {
-    const size_t sm = wgrad_smem_bytes<0, 8>();
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    if (e == hipSuccess) hipLaunchKernelGGL((conv3x3_wgrad_kernel<0, 8>), grid, block, sm, st, p);
-  } else if (mode == 1) {
-    const size_t sm = wgrad_smem_bytes<1, 4>();
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    if (e == hipSuccess) hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 4>), grid, block, sm, st, p);
+  if (pl.v2) {
+    if (mode == 0)      e = launch_dyn(conv3x3_wgrad_dma_kernel<0, 4>, grid, dim3(512), (size_t)2 * DmaGeom<0, 4>::BUF_F * sizeof(float), st, p);
+    else if (mode == 1) e = launch_dyn(conv3x3_wgrad_dma_kernel<1, 2>, grid, dim3(512), (size_t)2 * DmaGeom<1, 2>::BUF_F * sizeof(float), st, p);
+    else                e = launch_dyn(conv3x3_wgrad_dma_kernel<2, 4>, grid, dim3(512), (size_t)2 * DmaGeom<2, 4>::BUF_F * sizeof(float), st, p);
   } else {
-    const size_t sm = wgrad_smem_bytes<2, 8>();
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    if (e == hipSuccess) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 8>), grid, block, sm, st, p);
+    if (mode == 0)      e = launch_dyn(conv3x3_wgrad_kernel<0, 8>, grid, dim3(256), wgrad_smem_bytes<0, 8>(), st, p);
+    else if (mode == 1) e = launch_dyn(conv3x3_wgrad_kernel<1, 4>, grid, dim3(256), wgrad_smem_bytes<1, 4>(), st, p);
+    else                e = launch_dyn(conv3x3_wgrad_kernel<2, 8>, grid, dim3(256), wgrad_smem_bytes<2, 8>(), st, p);
   }
   if (e != hipSuccess) {
     odvae_set_error("conv3x3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
