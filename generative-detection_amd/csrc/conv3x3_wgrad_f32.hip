@@ -179,7 +179,7 @@ struct DmaGeom {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int MODE, int TH>
-__global__ __launch_bounds__(512) void conv3x3_wgrad_dma_kernel(WgradParams p) {
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_dma_kernel(WgradParams p) {
   using G = DmaGeom<MODE, TH>;
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 * BUF_F floats
 
@@ -244,19 +244,36 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_dma_kernel(WgradParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` have landed
     __syncthreads();                                    // everyone's have; buffer cur^1 is free again
     if (it + 1 < ntl) issue(t_beg + it + 1, cur ^ 1);
-    const float* xa = smem + cur * G::BUF_F + wm * 32 + li;            // [HPIX][64]
-    const float* db = smem + cur * G::BUF_F + G::XS_F + wn * 32 + li;  // [NPIX][128]
-#pragma unroll 4
-    for (int s = 0; s < G::NPIX / 2; ++s) {
-      const int px = 2 * s + h;
-      const int r = px / TW, c = px % TW;
-      const float b = db[px * BCO2];
-      if (do_bias) bsum += b;
+    // lane half h takes pixel 2s+h of k-step s; TW is even, so both halves sit in the same tile row
+    const float* xa = smem + cur * G::BUF_F + wm * 32 + li + h * BCI2;            // [HPIX][64]
+    const float* db = smem + cur * G::BUF_F + G::XS_F + wn * 32 + li + h * BCO2;  // [NPIX][128]
+    auto load_step = [&](int s, float (&a)[9], float& b) {
+      const int r = (2 * s) / TW, c = (2 * s) % TW;   // compile-time after unrolling
+      b = db[2 * s * BCO2];
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
-        const float a = xa[halo_index<MODE, TH>(r, c, t9 / 3, t9 % 3) * BCI2];
-        acc[t9] = mfma32(a, b, acc[t9]);
+        // halo_index is affine in c for every mode's even/odd pixel pair except MODE 2 (c >> 1): handle h there
+        int idx;
+        if (MODE == 2) idx = ((r + t9 / 3 + 1) >> 1) * Halo<2, TH>::W;   // column part added per lane below
+        else idx = halo_index<MODE, TH>(r, c, t9 / 3, t9 % 3);
+        if (MODE == 2) a[t9] = (xa - h * BCI2)[(idx + ((c + h + t9 % 3 + 1) >> 1)) * BCI2];
+        else a[t9] = xa[idx * BCI2 + (MODE == 1 ? h * BCI2 : 0)];        // MODE 1: pixel step is 2 halo columns
       }
+    };
+    float ac[9], an[9], bc, bn = 0.f;
+    load_step(0, ac, bc);
+#pragma unroll
+    for (int s = 0; s < G::NPIX / 2; ++s) {
+      // software pipeline, pinned: k-step s+1's ten LDS reads are in flight behind step s's nine MFMAs
+      if (s + 1 < G::NPIX / 2) load_step(s + 1, an, bn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_bias) bsum += bc;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) acc[t9] = mfma32(ac[t9], bc, acc[t9]);
+      __builtin_amdgcn_sched_barrier(0);
+      bc = bn;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) ac[t9] = an[t9];
     }
   }
 
