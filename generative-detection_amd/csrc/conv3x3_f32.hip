@@ -219,6 +219,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvParams p) {
   }
 }
 
+#ifdef ODVAE_STAMPS
+// Diagnostic build only (tools/conv_stamps.py): s_memtime stamps of the v2 kernel's phases, per wave, for the
+// first 4096 blocks.  Never compiled into libodvae_hip.so.
+__device__ unsigned long long g_stamps[4096 * 4 * 4];
+#define ODVAE_T() __builtin_amdgcn_s_memtime()
+#endif
+
 // ---- v2 main loop ------------------------------------------------------------------------------------
 // Same tiling and epilogue, different feeding: weight fragments go global/L2 -> registers directly (the pack
 // layout makes one coalesced 16-byte load per lane a whole B fragment for four k-steps; prefetched one k-group
@@ -260,27 +267,44 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float4 hreg[HALO_IT];
+  // Halo fetch.  Vector path: branch-free buffer loads -- a lane outside the image (or past Cin) points its
+  // offset beyond num_records and the hardware returns 0, so all HALO_IT loads are in flight together.  (A guarded
+  // `if (inside) v = load` makes hipcc branch around every load and wait vmcnt(0) at each join: stamps showed the
+  // prologue at 34k cycles.)  Scalar path only for Cin % 4 != 0 (the RGB input).
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xn), 0, p.Hi * p.Wi * p.Cin * 4, 0x00020000);
   auto load_halo = [&](int c0) {
+    if (vec) {
 #pragma unroll
-    for (int i = 0; i < HALO_IT; ++i) {
-      const int f = tid + 256 * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < HALO_F4) {
+      for (int i = 0; i < HALO_IT; ++i) {
+        const int f = tid + 256 * i;
         const int hp = f / QC, q = f % QC;
         const int iy = iy0 + hp / Halo<MODE>::W, ix = ix0 + hp % Halo<MODE>::W;
         const int c = c0 + 4 * q;
-        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin) {
-          const float* src = xn + ((int64_t)iy * p.Wi + ix) * p.Cin + c;
-          if (vec) v = *reinterpret_cast<const float4*>(src);
-          else {
+        const bool ok = f < HALO_F4 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin;
+        const unsigned voff = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + c) * 4) : 0x7FFFFFF0u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+        hreg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HALO_IT; ++i) {
+        const int f = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < HALO_F4) {
+          const int hp = f / QC, q = f % QC;
+          const int iy = iy0 + hp / Halo<MODE>::W, ix = ix0 + hp % Halo<MODE>::W;
+          const int c = c0 + 4 * q;
+          if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin) {
+            const float* src = xn + ((int64_t)iy * p.Wi + ix) * p.Cin + c;
             v.x = src[0];
             if (c + 1 < p.Cin) v.y = src[1];
             if (c + 2 < p.Cin) v.z = src[2];
             if (c + 3 < p.Cin) v.w = src[3];
           }
         }
+        hreg[i] = v;
       }
-      hreg[i] = v;
     }
   };
   auto store_halo = [&](float* Hs) {
@@ -318,10 +342,24 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
       if (MODE == 3 && !ok) a[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+#ifdef ODVAE_STAMPS
+  const unsigned long long st_start = ODVAE_T();
+  unsigned long long st_bar = 0;
+#endif
+  // weight fragments run TWO steps ahead (L2 latency under load exceeds one 16-MFMA step); bn2 is the far slot
+  float4 bn2[WNT];
+  auto load_b_step = [&](int ch, int it, bool valid, float4 (&b)[WNT]) {   // step `it` may spill into chunk ch+1
+    if (it < NIT) load_b(ch, it / NG, it % NG, b);
+    else if (valid) load_b(ch + 1, (it - NIT) / NG, (it - NIT) % NG, b);
+  };
   load_halo(0);
   load_b(0, 0, 0, bc);
+  load_b(0, 1 / NG, 1 % NG, bn);
   store_halo(smem);
   __syncthreads();
+#ifdef ODVAE_STAMPS
+  const unsigned long long st_loop = ODVAE_T();
+#endif
 
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* Hs = smem + (ch & 1) * HPIX * HS;
@@ -330,13 +368,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
     load_a(Hs, 0, ac);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      // software pipeline, pinned: operands of step it+1 are requested before step it's MFMAs are issued
-      if (it + 1 < NIT) {
-        load_b(ch, (it + 1) / NG, (it + 1) % NG, bn);
-        load_a(Hs, it + 1, an);
-      } else if (more) {
-        load_b(ch + 1, 0, 0, bn);
-      }
+      // software pipeline, pinned: B of step it+2 and A of step it+1 are requested before step it's MFMAs issue
+      load_b_step(ch, it + 2, more, bn2);
+      if (it + 1 < NIT) load_a(Hs, it + 1, an);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < WMT; ++mt)
@@ -349,37 +383,77 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < WNT; ++nt) bc[nt] = bn[nt];
+      for (int nt = 0; nt < WNT; ++nt) { bc[nt] = bn[nt]; bn[nt] = bn2[nt]; }
 #pragma unroll
       for (int mt = 0; mt < WMT; ++mt) ac[mt] = an[mt];
     }
+#ifdef ODVAE_STAMPS
+    const unsigned long long st_b0 = ODVAE_T();
+#endif
     if (more) store_halo(smem + ((ch + 1) & 1) * HPIX * HS);
     __syncthreads();
+#ifdef ODVAE_STAMPS
+    st_bar += ODVAE_T() - st_b0;
+#endif
   }
+#ifdef ODVAE_STAMPS
+  const unsigned long long st_mma = ODVAE_T();
+#endif
 
+  // Epilogue: every load (bias, residual) is issued up front and branch-free (clamped addresses), then the 64
+  // stores go out back to back.  vmcnt counts loads and stores in order, so a load between stores -- or hipcc's
+  // vmcnt(0) at the join of a guarded load -- makes each store wait out the previous store's full write latency
+  // (stamps: 89k cycles per block, a third of its lifetime, before this change).
   float* yn = p.y + (int64_t)n * p.Ho * p.Wo * p.Cout;
   const float* rn = p.residual ? p.residual + (int64_t)n * p.Ho * p.Wo * p.Cout : nullptr;
+  int co[WNT]; float bv[WNT];
 #pragma unroll
   for (int nt = 0; nt < WNT; ++nt) {
-    const int co = n0 + (wn * WNT + nt) * 32 + li;
-    if (co >= p.Cout) continue;
-    const float bv = p.bias ? p.bias[co] : 0.f;
+    co[nt] = n0 + (wn * WNT + nt) * 32 + li;
+    bv[nt] = p.bias ? p.bias[min(co[nt], p.Cout - 1)] : 0.f;
+  }
+  int opix[WMT][16];   // pixel offset (oy*Wo + ox), -1 when outside the image
 #pragma unroll
-    for (int mt = 0; mt < WMT; ++mt) {
+  for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
+      const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
+      opix[mt][r] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+    }
+  if (rn) {
+    float rv[WMT][WNT][16];
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[mt][nt][r] = rn[(int64_t)max(opix[mt][r], 0) * p.Cout + min(co[nt], p.Cout - 1)];
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rv[mt][nt][r];
+  }
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < WMT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
-        const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
-        if (oy < p.Ho && ox < p.Wo) {
-          const int64_t o = ((int64_t)oy * p.Wo + ox) * p.Cout + co;
-          float v = acc[mt][nt][r] + bv;
-          if (rn) v += rn[o];
-          if (p.act) v = fmaxf(v, 0.f);
-          yn[o] = v;
-        }
+        float v = acc[mt][nt][r] + bv[nt];
+        if (p.act) v = fmaxf(v, 0.f);
+        if (opix[mt][r] >= 0 && co[nt] < p.Cout) yn[(int64_t)opix[mt][r] * p.Cout + co[nt]] = v;
       }
-    }
+#ifdef ODVAE_STAMPS
+  if (blockIdx.y == 0 && blockIdx.x < 4096 && lane == 0) {
+    const unsigned long long st_done = ODVAE_T();
+    unsigned long long* o = g_stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+    o[0] = st_loop - st_start; o[1] = st_mma - st_loop; o[2] = st_bar; o[3] = st_done - st_mma;
   }
+#endif
 }
 
 // OIHW -> fwd pack [t][CinP/4][CoutP][4] and dgrad pack [t'][CoutP_d/4][CinP_d][4] (flipped taps)
@@ -415,6 +489,12 @@ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 }  // namespace
 
 extern "C" {
+
+#ifdef ODVAE_STAMPS
+int odvae_debug_read_stamps(unsigned long long* host, size_t count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), count * sizeof(unsigned long long));
+}
+#endif
 
 // padded reduction / output channel counts of a weight pack (reduce = channels summed over)
 int odvae_conv3x3_pack_reduce_pad(int c_reduce) { return round_up(c_reduce, 32); }
@@ -454,6 +534,7 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   if (mode == 1) ODVAE_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv3x3 mode 1: need even Hi,Wi and Ho=Hi/2");
   if (mode == 2 || mode == 3) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3 mode %d: need Ho=2*Hi", mode);
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wpk & 15) == 0, "conv3x3: x/wpk must be 16-byte aligned");
+  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 4 < 0x7FFFFFF0ll, "conv3x3: one input image must stay below 2 GiB");
 
   ConvParams p;
   p.x = x; p.wpk = wpk; p.bias = bias; p.residual = residual; p.y = y;

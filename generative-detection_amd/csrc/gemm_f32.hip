@@ -150,26 +150,49 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                         : p.C + batch * p.sC;
   const int ldc = to_partial ? p.N : p.ldc;
   const float* R = (!to_partial && p.residual) ? p.residual + batch * p.sC : nullptr;
+  // loads (bias, residual) first and branch-free, then nothing but stores: a load between stores, or the vmcnt(0)
+  // hipcc puts at the join of a guarded load, would make every store wait out the previous store's write latency
+  int col[2]; float bv[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    col[nt] = n0 + wn * 64 + nt * 32 + li;
+    bv[nt] = (!to_partial && p.bias) ? p.bias[min(col[nt], p.N - 1)] : 0.f;
+  }
+  const float alpha = to_partial ? 1.f : p.alpha;
+  if (R) {
+    float rv[2][2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(m0 + wm * 64 + mt * 32 + acc_row(r, lane), p.M - 1);
+          rv[mt][nt][r] = R[(int64_t)row * ldc + min(col[nt], p.N - 1)];
+        }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] * alpha + rv[mt][nt][r];
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= alpha;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = n0 + wn * 64 + nt * 32 + li;
-      if (col >= p.N) continue;
-      const float bv = (!to_partial && p.bias) ? p.bias[col] : 0.f;
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + mt * 32 + acc_row(r, lane);
-        if (row < p.M) {
-          float v = acc[mt][nt][r];
-          if (!to_partial) {
-            v = v * p.alpha + bv;
-            if (R) v += R[(int64_t)row * ldc + col];
-          }
-          C[(int64_t)row * ldc + col] = v;
-        }
+        if (row < p.M && col[nt] < p.N) C[(int64_t)row * ldc + col[nt]] = acc[mt][nt][r] + bv[nt];
       }
-    }
 }
 
 // sums the split-K slabs, then alpha / bias / residual
