@@ -132,5 +132,10 @@ def test_three_step_loss_curve_matches_oracle(hip_lib):
     assert model.global_step == 3 and ref.global_step == 3
     # weights after three Adam steps
     ref_sd = ref.state_dict()
-    worst = max(rel(v, ref_sd[k]) for k, v in model.state_dict().items() if v.dtype == torch.float32 and k.startswith(("encoder", "decoder", "quant", "post_quant", "pose_")))
-    assert worst < 5e-3, worst  # Adam's update is ~lr*sign(g) for near-zero gradients (attention k.bias): 3 steps * lr / |w|
+    # Adam's update is ~lr*sign(g): a gradient that is zero up to rounding (attention k.bias) may move a weight by
+    # up to 2*lr per step differently in two correct implementations
+    lr, steps = model.learning_rate, 3
+    for k, v in model.state_dict().items():
+        if v.dtype == torch.float32 and k.startswith(("encoder", "decoder", "quant", "post_quant", "pose_")):
+            diff = (v.detach().cpu().double() - ref_sd[k].double()).abs().max().item()
+            assert diff <= 2.2 * lr * steps + 5e-3 * ref_sd[k].abs().max().item(), (k, diff)

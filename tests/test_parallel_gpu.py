@@ -1,0 +1,66 @@
+"""Data-parallel path on device tensors: two ranks share the one GPU of the test box (gloo backend moves CUDA tensors
+through the host; RCCL refuses two ranks on one device), running the real PoseAutoencoder + FusedAdam + GradReducer +
+Trainer stack.  Checks that the bucketed all-reduce over the flat gradient arena keeps both ranks in lock-step and that
+every bucket is reduced.  The RCCL launch itself (`--gpus N`) can only be exercised on a multi-GPU node (bench.py)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+YAML = os.path.join(ROOT, "tests", "golden", "autoencoder_kl_16x16x16.yaml")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from odvae_amd import synthetic
+    from odvae_amd.trainer import Trainer
+    torch.manual_seed(1000 + rank)   # different initial weights per rank: the broadcast must align them
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32).to("cuda:0").train()
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), bucket_mb=4.0)
+    red = trainer.reducers[0]
+    losses = []
+    for step in range(2):
+        batch = synthetic.make_batch(2, 64, seed=50 + 10 * step + rank)   # each rank its own shard
+        model.injected_noise = synthetic.make_noise(2, 4, seed=70 + 10 * step + rank)
+        losses.append(trainer.training_batch(batch, step)[0].item())
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith(("encoder", "decoder", "quant", "post_quant", "pose_"))}
+    torch.save({"sd": sd, "losses": losses, "nbuckets": len(red.buckets), "order": list(red.launch_order)},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_lockstep(tmp_path):
+    # Spawning = fork + exec; on this GPU pool a process that has already initialised the GPU must not exec, so the
+    # test only runs when this pytest process has not touched the device yet (run the file on its own:
+    # `python -m pytest tests/test_parallel_gpu.py -m gpu`); device_count() does not initialise the GPU.
+    if torch.cuda.device_count() < 1:
+        pytest.skip("no HIP device")
+    if torch.cuda.is_initialized():
+        pytest.skip("GPU already initialised in this process; run this file in its own pytest invocation")
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert r0["nbuckets"] >= 2 and sorted(r0["order"]) == list(range(r0["nbuckets"])) and r0["order"] == r1["order"]
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k   # identical averaged gradients -> bit-identical weights
+    assert all(torch.isfinite(torch.tensor(r["losses"])).all() for r in (r0, r1))
+    assert r0["losses"] != r1["losses"]                  # the ranks really saw different shards

@@ -1,0 +1,35 @@
+"""Summarise a rocprofv3 --kernel-trace CSV of `bench.py` into per-kernel totals for the LAST training step
+(steps are delimited by the Adam launches).  Usage: python tools/summarize_trace.py <kernel_trace.csv> > profiles/xx.md"""
+import collections
+import csv
+import sys
+
+
+def main(path):
+    rows = list(csv.DictReader(open(path)))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
+    adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[2]]
+    groups = []
+    for i in adam:
+        if groups and i - groups[-1][-1] < 20:
+            groups[-1].append(i)
+        else:
+            groups.append([i])
+    seg = ev[groups[-2][-1] + 1:groups[-1][-1] + 1]
+    wall = (seg[-1][1] - seg[0][0]) / 1e6
+    busy = sum(b - a for a, b, _ in seg) / 1e6
+    by, cnt = collections.Counter(), collections.Counter()
+    for a, b, n in seg:
+        k = n.replace("(anonymous namespace)::", "").replace("void ", "")
+        k = k.split("(")[0] if not k.startswith("at::") else k[:70]
+        by[k] += (b - a) / 1e6
+        cnt[k] += 1
+    print("# rocprofv3 --kernel-trace, last training step of `bench.py` (B=32, 256x256, fp32, rec+KL only)\n")
+    print("step wall %.1f ms | kernel busy %.1f ms | idle %.1f ms | %d launches\n" % (wall, busy, wall - busy, len(seg)))
+    print("| kernel | launches | total ms | avg us | % of busy |\n|---|---:|---:|---:|---:|")
+    for k, v in by.most_common(40):
+        print("| `%s` | %d | %.2f | %.1f | %.1f |" % (k, cnt[k], v, 1e3 * v / cnt[k], 100 * v / busy))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
