@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--gan", action="store_true",
+                    help="BASELINE.json configs[3]: PatchGAN discriminator + LPIPS-style loss, both optimizers per batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
@@ -93,9 +95,10 @@ def main():
 
     torch.manual_seed(23)
     lat = args.res // 16
-    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat).to(dev)
+    gan = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if args.gan else {}
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gan).to(dev)
     model.train()
-    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,))
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if args.gan else (0,))
     batch = synthetic.make_batch(args.batch, args.res, seed=23 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}  # inputs resident in HBM
 
@@ -136,8 +139,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, rec+KL only (discriminator off, optimizer 0), VAE phase"
-                       % (args.res, args.res, args.batch),
+            "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
+                       % (args.res, args.res, args.batch,
+                          "PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
+                          else "rec+KL only (discriminator off, optimizer 0)"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         }
         if roof is not None:

@@ -262,12 +262,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
   }
 }
+// one wavefront per column: lanes stride over the partial blocks, f64 wave reduction (fixed order => deterministic)
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * C + c];
-  out[c] = (float)s;
+  for (int b = threadIdx.x & 63; b < nblk; b += 64) s += (double)part[(int64_t)b * C + c];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) out[c] = (float)s;
 }
 
 // ---- optimizer: global grad norm + Adam over one flat arena (src/models/autoencoder.py:365-377, yaml:140)
@@ -490,7 +492,7 @@ int odvae_colsum_f32(const float* x, int64_t rows, int C, float* out, void* work
   const int rpb = (int)ceil_div64(rows, nblk);
   const int nb = (int)ceil_div64(rows, rpb);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, rows, C, rpb, part);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nb, C, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nb, C, out);
   ODVAE_LAUNCH_CHECK("colsum");
   return ODVAE_OK;
 }
