@@ -146,9 +146,14 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         }
         if roof is not None:
+            traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
+            tpath = os.path.join(ROOT, "profiles", "r01_conv3x3_traffic.json")
+            if os.path.exists(tpath) and not args.gan and args.batch == 32 and args.res == 256:
+                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             out["roofline"] = {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                               "kernel": "conv3x3_kernel<MODE 0,KC 16,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)",
+                               "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv3x3_traffic.json)",
+                               "kernel": "conv3x3_kernel_v2<MODE 0,KC 32,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)",
                                "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
                                "algorithmic_gflop_per_launch": roof["gflop_per_launch"],
                                "share_of_step_time": roof["total_ms"] / (ms * args.steps)}

@@ -1,0 +1,33 @@
+"""Turn two rocprofv3 --pmc passes of `bench.py` (FETCH_SIZE, WRITE_SIZE) into profiles/r01_conv3x3_traffic.json:
+average HBM bytes per launch of the dominant kernel.  gfx950 corrections per MI355X_MICROARCH.md (HBM section):
+counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x, WRITE_SIZE is exact.
+Usage: python tools/collect_traffic.py <fetch_dir> <write_dir> <out.json>"""
+import csv
+import glob
+import json
+import sys
+
+KERNEL = "conv3x3_kernel_v2<0, 32, 2, 2, 2, 2, 1>"
+
+
+def per_launch(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(vals) / len(vals), len(vals)
+
+
+def main(fetch_dir, write_dir, out):
+    fetch_kib, n1 = per_launch(fetch_dir, "FETCH_SIZE")
+    write_kib, n2 = per_launch(write_dir, "WRITE_SIZE")
+    res = {"kernel": KERNEL, "launches_averaged": [n1, n2],
+           "FETCH_SIZE_KiB_per_launch_raw": fetch_kib, "WRITE_SIZE_KiB_per_launch_raw": write_kib,
+           "fetch_bytes_per_launch_corrected": 2.0 * fetch_kib * 1024.0, "write_bytes_per_launch": write_kib * 1024.0,
+           "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
+           "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 "
+                     "--no-cpu-baseline --no-kernel-events; FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes"}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
