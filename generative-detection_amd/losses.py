@@ -183,15 +183,30 @@ class PoseLoss(LPIPSWithDiscriminator):
             return mask_loss, self.mask_weight * mask_loss
         return torch.tensor(0.0), torch.tensor(0.0)
 
+    def _prior_table(self, device):
+        """Per-label prior moments stacked once: {label: row}, mean/var/logvar [L, 8] on `device`."""
+        cache = getattr(self, "_prior_cache", None)
+        if cache is None or cache[1].device != device:
+            labels = list(self.bbox_distribution_dict.keys())
+            rows = {lab: i for i, lab in enumerate(labels)}
+            stack = lambda attr: torch.stack([getattr(self.bbox_distribution_dict[l], attr).squeeze() for l in labels]).to(device)
+            cache = (rows, stack("mean"), stack("var"), stack("logvar"))
+            self._prior_cache = cache
+        return cache
+
     def compute_pose_kl_loss(self, bbox_posterior, mask_bg, class_gt):
-        mean, logvar = bbox_posterior.mean, bbox_posterior.logvar
-        kl = torch.zeros(len(class_gt), mean.size(1), device=mean.device)
-        for idx, label in enumerate(class_gt):  # host loop over the batch, as in the reference (:196-203)
-            if label == "background":
-                continue
-            cur = DiagonalGaussianDistribution(torch.cat((mean[idx].unsqueeze(1), logvar[idx].unsqueeze(1)), dim=1))
-            kl[idx] = cur.kl(self.bbox_distribution_dict[label])
-        return self._masked_mean(kl, mask_bg)
+        """The reference loops over the batch on the host (:196-203), calling kl(other) on [8,1] moments against
+        [1,8] prior moments.  QUIRK kept: that broadcast makes entry i of a sample's row the sum over ALL prior
+        dimensions j of the (i, j) cross term.  Evaluated here for the whole batch at once (same arithmetic, ~500
+        fewer tiny launches per step): [B,8,1] against [B,1,8] -> sum over j."""
+        mean, logvar = bbox_posterior.mean, bbox_posterior.logvar           # [B, 8]
+        rows, p_mean, p_var, p_logvar = self._prior_table(mean.device)
+        idx = torch.tensor([rows[l] if l != "background" else 0 for l in class_gt], device=mean.device)
+        keep = torch.tensor([0.0 if l == "background" else 1.0 for l in class_gt], device=mean.device)
+        om, ov, ol = p_mean[idx].unsqueeze(1), p_var[idx].unsqueeze(1), p_logvar[idx].unsqueeze(1)   # [B, 1, 8]
+        m, lv = mean.unsqueeze(2), logvar.unsqueeze(2)                                               # [B, 8, 1]
+        kl = 0.5 * torch.sum(torch.pow(m - om, 2) / (ov + 1e-5) + torch.exp(lv) / (ov + 1e-5) - 1.0 - lv + ol, dim=2)
+        return self._masked_mean(kl * keep.unsqueeze(1), mask_bg)
 
     # ---- reconstruction / KL terms on the image (contperceptual.py:134-164) ----------------------------------
     def _rec_sums(self, inputs_rgb, recon_rgb, mask_2d_bbox, use_pixel_loss):

@@ -5,6 +5,8 @@ parameters (checkpoint interchange with the reference) and are r
 torch supplies device memory, the current stream and autograd bookkeeping; every FLOP and every byte
 of the hot path moves through libodvae_hip.so.  No CPU fallback exists.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -86,8 +88,35 @@ KERNEL_EVENTS = _KernelEvents()
 # ------------------------------------------------------------------------------------------------------
 # 3x3 convolution family
 # ------------------------------------------------------------------------------------------------------
-def pack_conv3x3(weight, want_fwd=True, want_dgrad=False):
-    """OIHW parameter -> kernel packs (see conv3x3_f32.hip)."""
+class _PackCache:
+    """Weight packs keyed by (storage pointer, tensor version, optimizer epoch): a conv's forward and data-gradient packs
+    are built together, once per weight update, instead of once per call.  FusedAdam updates parameters from a raw
+    kernel (no torch version bump), so it advances `epoch` itself."""
+
+    def __init__(self):
+        self.epoch = 0
+        self.store = {}
+
+    def bump(self):
+        self.epoch += 1
+
+    def get(self, weight, want_dgrad):
+        key = id(weight)
+        tag = (weight.data_ptr(), weight._version, self.epoch)
+        hit = self.store.get(key)
+        if hit is not None and hit[0]() is weight and hit[1] == tag and (hit[3] is not None or not want_dgrad):
+            return hit[2], hit[3]
+        fwd, dgr = _pack_conv3x3_now(weight, True, want_dgrad)
+        if len(self.store) > 4096:   # transient weights (tests): drop entries whose tensor is gone
+            self.store = {k: v for k, v in self.store.items() if v[0]() is not None}
+        self.store[key] = (weakref.ref(weight), tag, fwd, dgr)
+        return fwd, dgr
+
+
+PACK_CACHE = _PackCache()
+
+
+def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False):
     L = _L()
     w = weight.detach().contiguous()
     _lib.require_device(w)
@@ -100,6 +129,12 @@ def pack_conv3x3(weight, want_fwd=True, want_dgrad=False):
     _lib.check(L.odvae_conv3x3_pack_f32(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()),
                "conv3x3_pack")
     return fwd, dgr
+
+
+def pack_conv3x3(weight, want_fwd=True, want_dgrad=False):
+    """OIHW parameter -> kernel packs (see conv3x3_f32.hip), cached per weight update."""
+    fwd, dgr = PACK_CACHE.get(weight, want_dgrad)
+    return (fwd if want_fwd else None), (dgr if want_dgrad else None)
 
 
 def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
@@ -128,7 +163,7 @@ class _Conv3x3(Function):
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
-        fwd_pack, _ = pack_conv3x3(weight, True, False)
+        fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]))  # both packs in one launch
         b = bias.detach().contiguous() if bias is not None else None
         y = _conv3x3_raw(mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
         ctx.mode = mode

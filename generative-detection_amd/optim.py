@@ -132,6 +132,8 @@ class FusedAdam(torch.optim.Optimizer):
                                              float(g0["eps"]), count, clip, _lib.stream_ptr()), "adam_step")
         self._touched.clear()
         self._clip_armed = False
+        from . import ops
+        ops.PACK_CACHE.bump()   # parameters changed under torch's version counters: conv weight packs are stale
         return loss
 
 
