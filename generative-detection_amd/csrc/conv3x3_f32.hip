@@ -258,13 +258,52 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
   const float* xn = p.x + (int64_t)n * p.Hi * p.Wi * p.Cin;
   const bool vec = (p.Cin & 3) == 0;
 
+  // Output addressing: 32-bit byte offsets into per-image buffer descriptors; a lane whose pixel or channel is
+  // outside gets an offset past num_records, which the hardware turns into "load 0" / "drop the store": no compares,
+  // no branches, no 64-bit math per element (the int64/branchy form cost ~25 VALU per store, 8k cycles per block).
+  const int img_bytes = p.Ho * p.Wo * p.Cout * 4;
+  const unsigned OOB = 0x7FFFFFF0u;
+  unsigned cobyte[WNT];
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt) {
+    const int co = n0 + (wn * WNT + nt) * 32 + li;
+    cobyte[nt] = co < p.Cout ? (unsigned)co * 4u : OOB;
+  }
+  auto pix_byte = [&](int mt, int r) -> unsigned {
+    const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
+    const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
+    return (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) * 4u : OOB;
+  };
+
+  // The accumulators START at bias + residual, so the epilogue is stores only: vmcnt counts loads and stores in
+  // order, and a load between stores (or hipcc's vmcnt(0) at the join of a guarded load) makes every store wait out
+  // the previous store's write latency -- s_memtime stamps showed 89k cycles of epilogue per 147k of MFMA that way.
   f32x16 acc[WMT][WNT];
+  {
+    float bv[WNT];
 #pragma unroll
-  for (int a = 0; a < WMT; ++a)
+    for (int nt = 0; nt < WNT; ++nt) bv[nt] = p.bias ? p.bias[min(n0 + (wn * WNT + nt) * 32 + li, p.Cout - 1)] : 0.f;
+    if (p.residual) {
+      const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(p.residual) + (int64_t)n * p.Ho * p.Wo * p.Cout, 0, img_bytes, 0x00020000);
 #pragma unroll
-    for (int b = 0; b < WNT; ++b)
+      for (int mt = 0; mt < WMT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const unsigned pb = pix_byte(mt, r);
+#pragma unroll
+          for (int nt = 0; nt < WNT; ++nt)
+            acc[mt][nt][r] = bv[nt] + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, pb + cobyte[nt], 0, 0));
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < WMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WNT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv[nt];
+    }
+  }
 
   float4 hreg[HALO_IT];
   // Halo fetch.  Vector path: branch-free buffer loads -- a lane outside the image (or past Cin) points its
@@ -400,53 +439,20 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
   const unsigned long long st_mma = ODVAE_T();
 #endif
 
-  // Epilogue: every load (bias, residual) is issued up front and branch-free (clamped addresses), then the 64
-  // stores go out back to back.  vmcnt counts loads and stores in order, so a load between stores -- or hipcc's
-  // vmcnt(0) at the join of a guarded load -- makes each store wait out the previous store's full write latency
-  // (stamps: 89k cycles per block, a third of its lifetime, before this change).
-  float* yn = p.y + (int64_t)n * p.Ho * p.Wo * p.Cout;
-  const float* rn = p.residual ? p.residual + (int64_t)n * p.Ho * p.Wo * p.Cout : nullptr;
-  int co[WNT]; float bv[WNT];
-#pragma unroll
-  for (int nt = 0; nt < WNT; ++nt) {
-    co[nt] = n0 + (wn * WNT + nt) * 32 + li;
-    bv[nt] = p.bias ? p.bias[min(co[nt], p.Cout - 1)] : 0.f;
-  }
-  int opix[WMT][16];   // pixel offset (oy*Wo + ox), -1 when outside the image
+  // Epilogue: stores only (bias and residual were folded into the accumulators' initial value)
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.Ho * p.Wo * p.Cout, 0, img_bytes, 0x00020000);
+  const bool relu = p.act != 0;
 #pragma unroll
   for (int mt = 0; mt < WMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
-      const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
-      opix[mt][r] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
-    }
-  if (rn) {
-    float rv[WMT][WNT][16];
+      const unsigned pb = pix_byte(mt, r);
 #pragma unroll
-    for (int mt = 0; mt < WMT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < WNT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rv[mt][nt][r] = rn[(int64_t)max(opix[mt][r], 0) * p.Cout + min(co[nt], p.Cout - 1)];
-#pragma unroll
-    for (int mt = 0; mt < WMT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < WNT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += rv[mt][nt][r];
-  }
-#pragma unroll
-  for (int nt = 0; nt < WNT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < WMT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[mt][nt][r] + bv[nt];
-        if (p.act) v = fmaxf(v, 0.f);
-        if (opix[mt][r] >= 0 && co[nt] < p.Cout) yn[(int64_t)opix[mt][r] * p.Cout + co[nt]] = v;
+      for (int nt = 0; nt < WNT; ++nt) {
+        const float v = acc[mt][nt][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(v, 0.f) : v), yrsrc, pb + cobyte[nt], 0, 0);
       }
+    }
 #ifdef ODVAE_STAMPS
   if (blockIdx.y == 0 && blockIdx.x < 4096 && lane == 0) {
     const unsigned long long st_done = ODVAE_T();
@@ -534,7 +540,8 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   if (mode == 1) ODVAE_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv3x3 mode 1: need even Hi,Wi and Ho=Hi/2");
   if (mode == 2 || mode == 3) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3 mode %d: need Ho=2*Hi", mode);
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wpk & 15) == 0, "conv3x3: x/wpk must be 16-byte aligned");
-  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 4 < 0x7FFFFFF0ll, "conv3x3: one input image must stay below 2 GiB");
+  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 4 < 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * 4 < 0x7FFFFFF0ll,
+                  "conv3x3: one input / output image must stay below 2 GiB");
 
   ConvParams p;
   p.x = x; p.wpk = wpk; p.bias = bias; p.residual = residual; p.y = y;

@@ -277,15 +277,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_dma_kernel(WgradParams p
     }
   }
 
+  // slab stores: 32-bit offsets into this split's slab; the tap stride goes into the scalar offset, so a store costs
+  // no per-element address arithmetic (144 stores per lane)
   const int co = co0 + wn * 32 + li;
   float* sl = p.slab + (int64_t)split * 9 * p.CinP * p.CoutP;
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(sl, 0, 9 * p.CinP * p.CoutP * 4, 0x00020000);
+  unsigned rowoff[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowoff[r] = (unsigned)((ci0 + wm * 32 + acc_row(r, lane)) * p.CoutP + co) * 4u;
+  const int tap_stride = p.CinP * p.CoutP * 4;
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = ci0 + wm * 32 + acc_row(r, lane);
-      sl[((int64_t)t9 * p.CinP + ci) * p.CoutP + co] = acc[t9][r];
-    }
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t9][r]), srsrc, rowoff[r], t9 * tap_stride, 0);
   if (do_bias) {
     bsum += __shfl_xor(bsum, 32, 64);
     if (h == 0) p.bslab[(int64_t)split * p.CoutP + co] = bsum;

@@ -98,13 +98,48 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, h = lane >> 5;
 
+  // Output addressing: 32-bit byte offsets into a buffer descriptor that starts at this block's first row; rows >= M
+  // and columns >= N get an offset past num_records (loads return 0, stores are dropped): no compares, no 64-bit
+  // math per element.  The accumulators START at the residual (the host guarantees alpha == 1 with a residual), so
+  // the epilogue is stores only -- vmcnt counts loads and stores in order; a load between stores serialises them.
+  const bool to_partial = p.partial != nullptr;
+  float* Cb = to_partial ? p.partial + ((int64_t)split * gridDim.z + batch) * (int64_t)p.M * p.N : p.C + batch * p.sC;
+  const int ldc = to_partial ? p.N : p.ldc;
+  const unsigned OOB = 0x7FFFFFF0u;
+  const int rows_here = min(BM, p.M - m0);
+  const int tile_bytes = ((rows_here - 1) * ldc + p.N) * 4;
+  unsigned colbyte[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = n0 + wn * 64 + nt * 32 + li;
+    colbyte[nt] = col < p.N ? (unsigned)col * 4u : OOB;
+  }
+  auto row_byte = [&](int mt, int r) -> unsigned {
+    const int row = wm * 64 + mt * 32 + acc_row(r, lane);   // within the block tile
+    return row < rows_here ? (unsigned)(row * ldc) * 4u : OOB;
+  };
+
   f32x16 acc[2][2];
+  if (!to_partial && p.residual) {
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual) + batch * p.sC + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rb_ = row_byte(mt, r);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, rb_ + colbyte[nt], 0, 0));
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
 
   float4 ra[4], rb[4];
   if (kbeg < kend) {
@@ -144,55 +179,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
   }
 
-  // epilogue: lane owns column (n0 + wn*64 + nt*32 + li); rows come from the register index
-  const bool to_partial = p.partial != nullptr;
-  float* C = to_partial ? p.partial + ((int64_t)split * gridDim.z + batch) * (int64_t)p.M * p.N
-                        : p.C + batch * p.sC;
-  const int ldc = to_partial ? p.N : p.ldc;
-  const float* R = (!to_partial && p.residual) ? p.residual + batch * p.sC : nullptr;
-  // loads (bias, residual) first and branch-free, then nothing but stores: a load between stores, or the vmcnt(0)
-  // hipcc puts at the join of a guarded load, would make every store wait out the previous store's write latency
-  int col[2]; float bv[2];
+  // epilogue: lane owns column (n0 + wn*64 + nt*32 + li); rows come from the register index.  Stores only.
+  const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(Cb + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
+  float bv[2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    col[nt] = n0 + wn * 64 + nt * 32 + li;
-    bv[nt] = (!to_partial && p.bias) ? p.bias[min(col[nt], p.N - 1)] : 0.f;
-  }
+  for (int nt = 0; nt < 2; ++nt)
+    bv[nt] = (!to_partial && p.bias) ? p.bias[min(n0 + wn * 64 + nt * 32 + li, p.N - 1)] : 0.f;
   const float alpha = to_partial ? 1.f : p.alpha;
-  if (R) {
-    float rv[2][2][16];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(m0 + wm * 64 + mt * 32 + acc_row(r, lane), p.M - 1);
-          rv[mt][nt][r] = R[(int64_t)row * ldc + min(col[nt], p.N - 1)];
-        }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = acc[mt][nt][r] * alpha + rv[mt][nt][r];
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= alpha;
-  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int r = 0; r < 16; ++r) {
+      const unsigned rb_ = row_byte(mt, r);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + acc_row(r, lane);
-        if (row < p.M && col[nt] < p.N) C[(int64_t)row * ldc + col[nt]] = acc[mt][nt][r] + bv[nt];
-      }
+      for (int nt = 0; nt < 2; ++nt)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * alpha + bv[nt]), crsrc, rb_ + colbyte[nt], 0, 0);
+    }
 }
 
 // sums the split-K slabs, then alpha / bias / residual
@@ -243,6 +245,8 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_f32: empty shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   ODVAE_CHECK_ARG(A && B && C, "gemm_f32: null operand");
   ODVAE_CHECK_ARG(batch <= 65535, "gemm_f32: batch %d > 65535", batch);
+  ODVAE_CHECK_ARG(!(residual && alpha != 1.f), "gemm_f32: a residual needs alpha == 1 (it seeds the accumulators)");
+  ODVAE_CHECK_ARG((int64_t)BM * ldc * 4 < 0x7FFFFFF0ll, "gemm_f32: ldc %d too large for 32-bit tile offsets", ldc);
   // float4 staging: the contiguous axis of each operand must be a multiple of 4 and 16-byte aligned
   ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0,
                   "gemm_f32: lda/ldb/strides must be multiples of 4 floats");

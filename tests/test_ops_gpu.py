@@ -40,12 +40,20 @@ def test_gemm(hip_lib, ta, tb, m, n, k, batch):
     b = torch.randn(batch, *((n, k) if tb else (k, n)), generator=g)
     bias = torch.randn(n, generator=g)
     res = torch.randn(batch, m, n, generator=g)
-    ref = 0.5 * torch.bmm(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b) + bias + res
+    prod = torch.bmm(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b)
     ad, bd, biasd, resd = a.to(dev()), b.to(dev()), bias.to(dev()), res.to(dev())
+    lda, sa, ldb, sb = a.shape[2], a.shape[1] * a.shape[2], b.shape[2], b.shape[1] * b.shape[2]
+    # bias + residual (the residual seeds the accumulators, which requires alpha == 1)
     c = torch.full((batch, m, n), float("nan"), device=dev())
-    ops.gemm(ta, tb, m, n, k, 0.5, ad, a.shape[2], a.shape[1] * a.shape[2], bd, b.shape[2], b.shape[1] * b.shape[2],
-             c, n, m * n, biasd, resd, batch)
-    close(c, ref, FWD_TOL * math.sqrt(k / 32), "gemm")
+    ops.gemm(ta, tb, m, n, k, 1.0, ad, lda, sa, bd, ldb, sb, c, n, m * n, biasd, resd, batch)
+    close(c, prod + bias + res, FWD_TOL * math.sqrt(k / 32), "gemm bias+residual")
+    # alpha + bias, no residual
+    c2 = torch.full((batch, m, n), float("nan"), device=dev())
+    ops.gemm(ta, tb, m, n, k, 0.5, ad, lda, sa, bd, ldb, sb, c2, n, m * n, biasd, None, batch)
+    close(c2, 0.5 * prod + bias, FWD_TOL * math.sqrt(k / 32), "gemm alpha+bias")
+    from odvae_amd import lib
+    with pytest.raises(lib.HipLibraryError):
+        ops.gemm(ta, tb, m, n, k, 0.5, ad, lda, sa, bd, ldb, sb, c2, n, m * n, biasd, resd, batch)
 
 
 def test_gemm_splitk(hip_lib):
