@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--gan", action="store_true",
                     help="BASELINE.json configs[3]: PatchGAN discriminator + LPIPS-style loss, both optimizers per batch")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal on one GPU: initialise RCCL with world size 1 and run the bucketed reducer anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
@@ -80,6 +82,11 @@ def cpu_baseline(res, batch=1, steps=1):
 
 def main():
     args = parse()
+    # RCCL prints banner lines ("Hostname", "Librccl path") on fd 1; the contract is ONE JSON line on stdout, so
+    # everything else that lands on fd 1 is routed to stderr and the result is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,9 +94,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
     from odvae_amd import ops, synthetic
     from odvae_amd.trainer import Trainer
 
@@ -98,7 +108,8 @@ def main():
     gan = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if args.gan else {}
     model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gan).to(dev)
     model.train()
-    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if args.gan else (0,))
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if args.gan else (0,),
+                      process_group=dist.group.WORLD if use_dist else None)
     batch = synthetic.make_batch(args.batch, args.res, seed=23 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}  # inputs resident in HBM
 
@@ -110,7 +121,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_kernel_events:
@@ -119,11 +130,11 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -160,8 +171,9 @@ def main():
         print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
