@@ -201,11 +201,11 @@ class PoseAutoencoder(AutoencoderKL):
         return self.dropout_prob_final
 
     def _dropout(self, z, p):
-        """nn.Dropout(p) in training mode: keep with prob 1-p, scale by 1/(1-p); p = 1 zeroes z."""
+        """nn.Dropout(p) keeps with prob 1-p and scales by 1/(1-p); p = 1 zeroes z.  QUIRK kept (autoencoder.py:233-235):
+        the reference builds a fresh nn.Dropout inside forward, and a fresh module is in training mode, so the dropout
+        is active in validation and log_images too."""
         mask = self._noise("dropout_mask")
         if mask is None:
-            if not self.training:
-                return z
             if p >= 1.0:
                 mask = torch.zeros(z.shape)
             else:

@@ -110,8 +110,10 @@ class PoseAutoencoder(nn.Module):
         posterior_obj, pose_feat = self.encode(input_im)
         z_obj = posterior_obj.sample(noise["posterior_eps"])
         self.dropout_prob = self._get_dropout_prob()
-        if self.dropout_prob > 0 and training:
-            z_obj = z_obj * noise["dropout_mask"]      # nn.Dropout(p)(z) with the drawn mask made explicit
+        if self.dropout_prob > 0:
+            # nn.Dropout(p)(z) with the drawn mask made explicit.  The reference constructs the Dropout module inside
+            # forward (:233-235); a fresh module is in training mode, so this applies in eval / log_images as well.
+            z_obj = z_obj * noise["dropout_mask"]
         if self.add_noise_to_z_obj:
             z_obj = z_obj + noise["z_noise"]
         z = self.pose_decoder(pose_feat.view(pose_feat.size(0), -1))

@@ -1,0 +1,51 @@
+"""The untouched reference yaml end to end on the GPU: thin runner (config merge + dotlist + lr rule + PL loop) in the
+encoder-pre-training phase the yaml starts in, and log_images against the oracle's decode."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+YAML = os.path.join(ROOT, "tests", "golden", "autoencoder_kl_16x16x16.yaml")
+
+
+def test_runner_with_untouched_yaml_phase_one(hip_lib):
+    from odvae_amd import run
+    model = run.main(["-b", YAML, "--steps", "2", "--height", "64", "model.params.ddconfig.ch=32", "data.params.batch_size=2"])
+    assert model.global_step == 4                       # two optimizers per batch
+    assert abs(model.learning_rate - 1 * 1 * 2 * 4.5e-6) < 1e-12
+    logs = model.logged_metrics
+    assert float(logs["dropout_prob"]) == 1.0           # phase 1: dropout p = 1, decoder skipped, pose losses only
+    assert float(logs["train/d_weight"]) == 0.0
+    assert torch.isfinite(logs["train/total_loss"]) and torch.isfinite(logs["train/disc_loss"])
+    # phase 1 trains only what feeds the pose head: decoder weights untouched by Adam
+    assert model.loss.encoder_pretrain_steps == 30000 and model.encoder_pretrain_steps == 30000
+
+
+def test_log_images_matches_oracle_decode(hip_lib):
+    from odvae_amd import synthetic
+    from oracle.autoencoder import PoseAutoencoder as OraclePA
+    torch.manual_seed(3)
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32)
+    mcfg, _ = synthetic.model_config(YAML, latent_hw=4, ch=32)
+    p = mcfg.params.to_container()
+    ref = OraclePA(p["ddconfig"], dict(p["lossconfig"]["params"]), p["embed_dim"], p["pose_decoder_config"]["params"],
+                   p["pose_encoder_config"]["params"], feat_dims=p["feat_dims"], dropout_prob_final=p["dropout_prob_final"],
+                   dropout_warmup_steps=p["dropout_warmup_steps"],
+                   pose_conditioned_generation_steps=p["pose_conditioned_generation_steps"])
+    ref.load_state_dict(model.state_dict())
+    model = model.to("cuda:0").eval(); ref.eval()
+    batch = synthetic.make_batch(2, 64, seed=9)
+    noise = synthetic.make_noise(2, 4, seed=10)
+    model.injected_noise = noise
+    out = model.log_images({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    assert set(out) == {"reconstructions_rgb", "perturbed_pose_reconstruction_rgb", "inputs_rgb"}
+    x = ref._rescale(batch["patch"].float())
+    with torch.no_grad():
+        dec_obj, dec_pose, post, _ = ref.forward(x, noise, training=False)
+    err = (out["inputs_rgb"].cpu() - x).abs().max().item()
+    assert err < 1e-5, err
+    rec = out["reconstructions_rgb"].cpu()
+    assert (rec - dec_obj).abs().max().item() <= 1e-3 * max(1.0, dec_obj.abs().max().item())
+    assert tuple(out["perturbed_pose_reconstruction_rgb"].shape) == (2, 3, 64, 64)
