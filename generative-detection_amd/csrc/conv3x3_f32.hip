@@ -269,9 +269,21 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
     const int co = n0 + (wn * WNT + nt) * 32 + li;
     cobyte[nt] = co < p.Cout ? (unsigned)co * 4u : OOB;
   }
+  // Tile pixel of row i of M-tile `mtg` (0..3).  MODE 3 (transposed stride-2 conv): an M-tile holds the 32 pixels of ONE
+  // parity class (py, px) of the 8x16 patch, so whether tap (kh, kw) reads a real dy pixel or an inserted zero is the
+  // same for the whole tile and the all-zero tap-tiles are skipped (9 of 36 remain).  Classes are paired 0:(0,0) 1:(1,1)
+  // 2:(0,1) 3:(1,0) so that each wave of the 2x2 layout gets 5 resp. 4 live tap-tiles.
+  auto tile_pixel = [&](int mtg, int i, int& r, int& c) {
+    if (MODE == 3) { r = 2 * (i >> 3) + (mtg & 1); c = 2 * (i & 7) + (((mtg + 1) >> 1) & 1); }
+    else { const int pm = mtg * 32 + i; r = pm / TW; c = pm % TW; }
+  };
+  auto tap_live = [&](int mtg, int kh, int kw) -> bool {
+    return MODE != 3 || ((((mtg & 1) + kh) | ((((mtg + 1) >> 1) & 1) + kw)) & 1) == 0;
+  };
   auto pix_byte = [&](int mt, int r) -> unsigned {
-    const int pm = (wm * WMT + mt) * 32 + acc_row(r, lane);
-    const int oy = oy0 + pm / TW, ox = ox0 + pm % TW;
+    int pr, pc;
+    tile_pixel(wm * WMT + mt, acc_row(r, lane), pr, pc);
+    const int oy = oy0 + pr, ox = ox0 + pc;
     return (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) * 4u : OOB;
   };
 
@@ -374,11 +386,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
     const int tap = it / NG, g = it % NG;
 #pragma unroll
     for (int mt = 0; mt < WMT; ++mt) {
-      const int pm = (wm * WMT + mt) * 32 + li;
+      int pr, pc;
+      tile_pixel(wm * WMT + mt, li, pr, pc);
       bool ok;
-      const int off = halo_index<MODE>(pm / TW, pm % TW, tap / 3, tap % 3, ok) * HS + 4 * h + 8 * g;
-      a[mt] = *reinterpret_cast<const float4*>(Hs + off);
-      if (MODE == 3 && !ok) a[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int off = halo_index<MODE>(pr, pc, tap / 3, tap % 3, ok) * HS + 4 * h + 8 * g;
+      a[mt] = *reinterpret_cast<const float4*>(Hs + off);   // MODE 3: dead taps read a harmless in-range pixel
     }
   };
 #ifdef ODVAE_STAMPS
@@ -412,7 +424,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
       if (it + 1 < NIT) load_a(Hs, it + 1, an);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < WMT; ++mt)
+      for (int mt = 0; mt < WMT; ++mt) {
+        // MODE 3 only; readfirstlane makes the predicate provably wave-uniform (a scalar branch, never an EXEC mask
+        // around MFMAs)
+        if (!tap_live(__builtin_amdgcn_readfirstlane(wm) * WMT + mt, (it / NG) / 3, (it / NG) % 3)) continue;
 #pragma unroll
         for (int nt = 0; nt < WNT; ++nt) {
           acc[mt][nt] = mfma32(ac[mt].x, bc[nt].x, acc[mt][nt]);
@@ -420,6 +435,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
           acc[mt][nt] = mfma32(ac[mt].z, bc[nt].z, acc[mt][nt]);
           acc[mt][nt] = mfma32(ac[mt].w, bc[nt].w, acc[mt][nt]);
         }
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < WNT; ++nt) { bc[nt] = bn[nt]; bn[nt] = bn2[nt]; }
@@ -571,6 +587,8 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
     switch (mode) {
       case 0:
         if (variant == 3 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 16, 2, 2, 2, 2, 3>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
+        else if (variant == 4 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 32, 4, 1, 1, 4>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
+        else if (variant == 5 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 16, 4, 1, 1, 4>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
         else if (variant == 2) { ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 16); }
         else { ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 32); }
         break;
