@@ -167,6 +167,7 @@ def main():
                                "kernel": "conv3x3_kernel_v2<MODE 0,KC 32,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)",
                                "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
                                "algorithmic_gflop_per_launch": roof["gflop_per_launch"],
+                               "algorithmic_bytes_per_launch": roof["bytes_per_launch"],
                                "share_of_step_time": roof["total_ms"] / (ms * args.steps)}
         print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:

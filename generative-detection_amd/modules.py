@@ -9,6 +9,7 @@ their forward is never called -- all arithmetic goes through generative-detectio
 """
 import torch
 import torch.nn as nn
+import torch.utils.checkpoint
 
 from . import ops
 
@@ -178,8 +179,11 @@ class Encoder(nn.Module):
 class Decoder(nn.Module):
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
                  resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
-                 use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+                 use_linear_attn=False, attn_type="vanilla", activation_checkpoint=False, **ignorekwargs):
         super().__init__()
+        # activation_checkpoint (not an upstream key; upstream swallows unknown keys through **ignorekwargs): keep only
+        # the input of each ResnetBlock(+AttnBlock) unit and recompute its interior in backward (BASELINE.json config 5).
+        self.activation_checkpoint = bool(activation_checkpoint)
         if use_linear_attn:
             attn_type = "linear"
         if tanh_out:
@@ -219,13 +223,14 @@ class Decoder(nn.Module):
     def forward(self, z):
         self.last_z_shape = z.shape
         h = self.conv_in(z)
-        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        recompute = self.activation_checkpoint and torch.is_grad_enabled() and h.requires_grad
+        run = (lambda f, t: torch.utils.checkpoint.checkpoint(f, t, use_reentrant=False)) if recompute else (lambda f, t: f(t))
+        h = run(lambda t: self.mid.block_2(self.mid.attn_1(self.mid.block_1(t))), h)
         for level in reversed(range(self.num_resolutions)):
             stage = self.up[level]
             for i, block in enumerate(stage.block):
-                h = block(h)
-                if len(stage.attn) > 0:
-                    h = stage.attn[i](h)
+                unit = (lambda t, b=block, a=stage.attn[i]: a(b(t))) if len(stage.attn) > 0 else block
+                h = run(unit, h)
             if level != 0:
                 h = stage.upsample(h)
         if self.give_pre_end:

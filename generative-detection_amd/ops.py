@@ -64,22 +64,23 @@ class _KernelEvents:
         ev.record()
         return ev
 
-    def end(self, name, flops, ev0):
+    def end(self, name, flops, ev0, nbytes=0.0):
         if ev0 is None:
             return
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        self.rec.setdefault(name, []).append((flops, ev0, ev1))
+        self.rec.setdefault(name, []).append((flops, ev0, ev1, nbytes))
 
     def summary(self, name):
         torch.cuda.synchronize()
         items = self.rec.get(name, [])
         if not items:
             return None
-        total_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in items)
-        flops = sum(f for f, _, _ in items)
+        total_ms = sum(it[1].elapsed_time(it[2]) for it in items)
+        flops = sum(it[0] for it in items)
         return {"launches": len(items), "total_ms": total_ms, "avg_ms": total_ms / len(items),
-                "gflop_per_launch": flops / len(items) / 1e9, "tflops": flops / total_ms / 1e9}
+                "gflop_per_launch": flops / len(items) / 1e9, "tflops": flops / total_ms / 1e9,
+                "bytes_per_launch": sum(it[3] for it in items) / len(items)}
 
 
 KERNEL_EVENTS = _KernelEvents()
@@ -151,7 +152,8 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
     _lib.check(L.odvae_conv3x3_f32(mode, x.data_ptr(), n, hi, wi, cin, pack.data_ptr(), cout,
                                    _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, int(act), _lib.stream_ptr()),
                "conv3x3(mode=%d)" % mode)
-    KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * ho * wo, tag)
+    KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * ho * wo, tag,
+                      4.0 * (n * hi * wi * cin + n * ho * wo * cout * (2 if residual is not None else 1) + 9 * cin * cout))
     return y
 
 
