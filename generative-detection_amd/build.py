@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(HERE, "libodvae_hip.so")
 HIP_SOURCES = ["gemm_f32.hip", "conv3x3_f32.hip", "conv3x3_wgrad_f32.hip", "groupnorm.hip", "elementwise.hip",
-               "gan_f32.hip", "lpips_f32.hip", "attention_f32.hip"]
+               "gan_f32.hip", "lpips_f32.hip", "patch_u8.hip"]
 CXX_SOURCES = ["runtime.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", CSRC]

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "odvae_maxpool2x2_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "odvae_lpips_distance_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "odvae_lpips_distance_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "odvae_patch_table_ints": (_I, [_I]),
+    "odvae_patch_crop_resize_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
 

@@ -149,6 +149,17 @@ int odvae_lpips_distance_f32(const float* f0, const float* f1, const float* w, f
 int odvae_lpips_distance_bwd_f32(const float* f0, const float* f1, const float* w, const float* g, float* df1,
                                  int N, int HW, int C, void* stream);
 
+/* ---- patch_u8.hip: object-patch extraction (src/data/datasets/nuscenes.py:159-192) ------------ */
+/* Replaces img_pil.crop(box) (:159) -> patch.resize((S, S), BILINEAR, reducing_gap=1.0) (:176) -> ToTensor (:190-191) and
+   the NEAREST-resized 2-d box mask (:178-192), bit-identical to Pillow's 8-bit fixed-point resampler.
+   d_images [B] device pointers to u8 HWC RGB camera images; d_geom [B][8] int32 {img_h, img_w, crop_x1, crop_y1, crop_size,
+   table_slot, 0, 0}; d_mask_rect [B][4] int32 {x_start, x_stop, y_start, y_stop} in crop coordinates; d_tables
+   [n_slots][S][8] int32 per crop size {k0..k4 (coefficients * 2^22), first source index, taps, nearest source index};
+   patch [B][S][S][3] f32 in [0,1], mask [B][S][S] f32 in {0,1}.  odvae_patch_table_ints(S) = ints per table slot. */
+int odvae_patch_table_ints(int S);
+int odvae_patch_crop_resize_u8(const void* d_images, const void* d_geom, const void* d_mask_rect, const void* d_tables,
+                               int n_slots, int B, int S, void* patch, void* mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
