@@ -34,11 +34,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const float* xn = x + (int64_t)n * s.HW * s.C + 4 * q;
   float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sq = sm;
   if (psub < s.pix_per_pass) {
-    for (int px = p_beg + psub; px < p_end; px += s.pix_per_pass) {
-      const float4 v = *reinterpret_cast<const float4*>(xn + (int64_t)px * s.C);
+    auto add = [&](const float4 v) {
       sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
       sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    };
+    const int64_t step = (int64_t)s.pix_per_pass * s.C;
+    const float* ptr = xn + (int64_t)(p_beg + psub) * s.C;
+    int px = p_beg + psub;
+    for (; px + 3 * s.pix_per_pass < p_end; px += 4 * s.pix_per_pass, ptr += 4 * step) {   // four loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(ptr), v1 = *reinterpret_cast<const float4*>(ptr + step);
+      const float4 v2 = *reinterpret_cast<const float4*>(ptr + 2 * step), v3 = *reinterpret_cast<const float4*>(ptr + 3 * step);
+      add(v0); add(v1); add(v2); add(v3);
     }
+    for (; px < p_end; px += s.pix_per_pass, ptr += step) add(*reinterpret_cast<const float4*>(ptr));
     *reinterpret_cast<float4*>(&red[0][psub * s.C + 4 * q]) = sm;
     *reinterpret_cast<float4*>(&red[1][psub * s.C + 4 * q]) = sq;
   }
@@ -77,30 +85,61 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, GnShape s,
 }
 
 // ---- forward apply -------------------------------------------------------------------------------
+// grid (blocks, N): no 64-bit index arithmetic; with 256 % quads == 0 (C = 128/256/512) a thread keeps one channel quad,
+// so gamma/beta/mean/rstd are loop-invariant registers and the loop is four independent 16-byte loads in flight
+struct GnQuad { float g[4], b[4], mu[4], rs[4], ds1[4], ds2[4]; };
+
+__device__ __forceinline__ void gn_load_quad(const GnShape& s, int n, int q, const float* gamma, const float* beta,
+                                             const float* mean, const float* rstd, const float* grp, GnQuad& k) {
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * q);
+  const float4 be = *reinterpret_cast<const float4*>(beta + 4 * q);
+  k.g[0] = ga.x; k.g[1] = ga.y; k.g[2] = ga.z; k.g[3] = ga.w;
+  k.b[0] = be.x; k.b[1] = be.y; k.b[2] = be.z; k.b[3] = be.w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = (4 * q + j) / s.cpg;
+    k.mu[j] = mean[n * s.G + g]; k.rs[j] = rstd[n * s.G + g];
+    if (grp) { k.ds1[j] = grp[((int64_t)n * s.G + g) * 2 + 0]; k.ds2[j] = grp[((int64_t)n * s.G + g) * 2 + 1]; }
+  }
+}
+
+template <bool SWISH>
+__device__ __forceinline__ float4 gn_apply_quad(const float4 v, const GnQuad& k) {
+  const float in[4] = {v.x, v.y, v.z, v.w};
+  float out[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float u = (in[j] - k.mu[j]) * k.rs[j] * k.g[j] + k.b[j];
+    out[j] = SWISH ? swish_f(u) : u;
+  }
+  return make_float4(out[0], out[1], out[2], out[3]);
+}
+
 template <bool SWISH>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, GnShape s,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        float* __restrict__ y) {
-  const int64_t per_n = (int64_t)s.HW * s.quads;
-  const int64_t total = per_n * s.N;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int n = (int)(idx / per_n);
-    const int q = (int)(idx % s.quads);
-    const int c = 4 * q;
-    const float4 v = *reinterpret_cast<const float4*>(x + idx * 4);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 be = *reinterpret_cast<const float4*>(beta + c);
-    float in[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, out[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int g = (c + j) / s.cpg;
-      const float mu = mean[n * s.G + g], rs = rstd[n * s.G + g];
-      const float u = (in[j] - mu) * rs * gg[j] + bb[j];
-      out[j] = SWISH ? swish_f(u) : u;
+  const int n = blockIdx.y;
+  const int per_n = s.HW * s.quads;
+  const float4* xn = reinterpret_cast<const float4*>(x) + (int64_t)n * per_n;
+  float4* yn = reinterpret_cast<float4*>(y) + (int64_t)n * per_n;
+  const int stride = gridDim.x * 256;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  GnQuad k;
+  if (256 % s.quads == 0) {
+    gn_load_quad(s, n, threadIdx.x % s.quads, gamma, beta, mean, rstd, nullptr, k);
+    for (; i + 3 * stride < per_n; i += 4 * stride) {
+      const float4 v0 = xn[i], v1 = xn[i + stride], v2 = xn[i + 2 * stride], v3 = xn[i + 3 * stride];
+      yn[i] = gn_apply_quad<SWISH>(v0, k); yn[i + stride] = gn_apply_quad<SWISH>(v1, k);
+      yn[i + 2 * stride] = gn_apply_quad<SWISH>(v2, k); yn[i + 3 * stride] = gn_apply_quad<SWISH>(v3, k);
     }
-    *reinterpret_cast<float4*>(y + idx * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    for (; i < per_n; i += stride) yn[i] = gn_apply_quad<SWISH>(xn[i], k);
+  } else {
+    for (; i < per_n; i += stride) {
+      gn_load_quad(s, n, i % s.quads, gamma, beta, mean, rstd, nullptr, k);
+      yn[i] = gn_apply_quad<SWISH>(xn[i], k);
+    }
   }
 }
 
@@ -195,44 +234,59 @@ __global__ void gn_bwd_param_kernel(const float* __restrict__ chan, int N, int C
   dbeta[c] = (float)b;
 }
 
-// dx = rstd * (du*gamma - (ds2 + xhat*ds1)/m)
+// dx = rstd * (du*gamma - (ds2 + xhat*ds1)/m); same launch shape as gn_apply_kernel
+template <bool SWISH>
+__device__ __forceinline__ float4 gn_bwd_quad(const float4 xv, const float4 dv, const GnQuad& k, float inv_m) {
+  const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+  float out[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xh = (xi[j] - k.mu[j]) * k.rs[j];
+    const float du = di[j] * act_grad<SWISH>(xh * k.g[j] + k.b[j]);
+    out[j] = k.rs[j] * (du * k.g[j] - (k.ds2[j] + xh * k.ds1[j]) * inv_m);
+  }
+  return make_float4(out[0], out[1], out[2], out[3]);
+}
+
 template <bool SWISH>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, GnShape s,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ grp, float* __restrict__ dx) {
-  const int64_t per_n = (int64_t)s.HW * s.quads;
-  const int64_t total = per_n * s.N;
+                                                           const float* __restrict__ grp, const float* __restrict__ dx_add,
+                                                           float* __restrict__ dx) {
+  const int n = blockIdx.y;
+  const int per_n = s.HW * s.quads;
+  const float4* xn = reinterpret_cast<const float4*>(x) + (int64_t)n * per_n;
+  const float4* dn = reinterpret_cast<const float4*>(dy) + (int64_t)n * per_n;
+  const float4* an = dx_add ? reinterpret_cast<const float4*>(dx_add) + (int64_t)n * per_n : nullptr;
+  auto plus = [&](float4 v, int at) {
+    if (an) { const float4 a = an[at]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    return v;
+  };
+  float4* on = reinterpret_cast<float4*>(dx) + (int64_t)n * per_n;
   const float inv_m = 1.f / ((float)s.HW * (float)s.cpg);
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int n = (int)(idx / per_n);
-    const int q = (int)(idx % s.quads);
-    const int c = 4 * q;
-    const float4 xv = *reinterpret_cast<const float4*>(x + idx * 4);
-    const float4 dv = *reinterpret_cast<const float4*>(dy + idx * 4);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 be = *reinterpret_cast<const float4*>(beta + c);
-    const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
-    const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-    float out[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int g = (c + j) / s.cpg;
-      const float mu = mean[n * s.G + g], rs = rstd[n * s.G + g];
-      const float ds1 = grp[((int64_t)n * s.G + g) * 2 + 0], ds2 = grp[((int64_t)n * s.G + g) * 2 + 1];
-      const float xh = (xi[j] - mu) * rs;
-      const float du = di[j] * act_grad<SWISH>(xh * gg[j] + bb[j]);
-      out[j] = rs * (du * gg[j] - (ds2 + xh * ds1) * inv_m);
+  const int stride = gridDim.x * 256;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  GnQuad k;
+  if (256 % s.quads == 0) {
+    gn_load_quad(s, n, threadIdx.x % s.quads, gamma, beta, mean, rstd, grp, k);
+    for (; i + stride < per_n; i += 2 * stride) {
+      const float4 x0 = xn[i], x1 = xn[i + stride], d0 = dn[i], d1 = dn[i + stride];
+      on[i] = plus(gn_bwd_quad<SWISH>(x0, d0, k, inv_m), i); on[i + stride] = plus(gn_bwd_quad<SWISH>(x1, d1, k, inv_m), i + stride);
     }
-    *reinterpret_cast<float4*>(dx + idx * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    for (; i < per_n; i += stride) on[i] = plus(gn_bwd_quad<SWISH>(xn[i], dn[i], k, inv_m), i);
+  } else {
+    for (; i < per_n; i += stride) {
+      gn_load_quad(s, n, i % s.quads, gamma, beta, mean, rstd, grp, k);
+      on[i] = plus(gn_bwd_quad<SWISH>(xn[i], dn[i], k, inv_m), i);
+    }
   }
 }
 
 bool make_shape(int N, int HW, int C, int G, GnShape& s) {
   if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0 || C % 4 != 0) return false;
   s.N = N; s.HW = HW; s.C = C; s.G = G; s.cpg = C / G; s.quads = C / 4;
-  if (s.quads > 256 || G > 256) return false;
+  if (s.quads > 256 || G > 256 || (int64_t)HW * s.quads >= ((int64_t)1 << 31) || N > 65535) return false;
   s.pix_per_pass = 256 / s.quads;
   // aim for >= ~2048 blocks overall, at least 64 pixels per block
   int chunks = ceil_div(2048, N);
@@ -244,7 +298,8 @@ bool make_shape(int N, int HW, int C, int G, GnShape& s) {
   return true;
 }
 
-int grid_1d(int64_t work_items) { return (int)std::min<int64_t>(ceil_div64(work_items, 256), 8192); }
+// x-dimension of the (blocks, N) apply grids: about eight float4 per thread
+int apply_blocks(const GnShape& s) { return (int)std::min<int64_t>(std::max<int64_t>(ceil_div64((int64_t)s.HW * s.quads, 256 * 8), 1), 65535); }
 
 }  // namespace
 
@@ -279,9 +334,9 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
   ODVAE_LAUNCH_CHECK("groupnorm stats");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(N * G, 256)), dim3(256), 0, st, partial, s, eps, mean, rstd);
   ODVAE_LAUNCH_CHECK("groupnorm finalize");
-  const int blocks = grid_1d((int64_t)N * HW * s.quads);
-  if (swish) hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(blocks), dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
-  else       hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(blocks), dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  const dim3 grid(apply_blocks(s), N);
+  if (swish) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  else       hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
   ODVAE_LAUNCH_CHECK("groupnorm apply");
   return ODVAE_OK;
 }
@@ -289,12 +344,13 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
 // dx, dgamma[C], dbeta[C] from dy (gradient w.r.t. the activated output), x and the saved mean/rstd
 int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
-                            float* dx, float* dgamma, float* dbeta,
+                            float* dx, float* dgamma, float* dbeta, const float* dx_add,
                             void* workspace, size_t workspace_bytes, void* stream) {
   GnShape s;
   ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_bwd: unsupported shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
   ODVAE_CHECK_ARG(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta, "groupnorm_bwd: null operand");
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0, "groupnorm_bwd: operands must be 16-byte aligned");
+  ODVAE_CHECK_ARG(((uintptr_t)dx_add & 15) == 0, "groupnorm_bwd: dx_add must be 16-byte aligned");
   const size_t need = odvae_groupnorm_workspace_bytes(N, HW, C, G);
   if (!workspace || workspace_bytes < need) {
     odvae_set_error("groupnorm_bwd: needs %zu workspace bytes, got %zu", need, workspace_bytes);
@@ -311,9 +367,9 @@ int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int 
   ODVAE_LAUNCH_CHECK("groupnorm bwd finalize");
   hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
   ODVAE_LAUNCH_CHECK("groupnorm bwd param");
-  const int blocks = grid_1d((int64_t)N * HW * s.quads);
-  if (swish) hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), dim3(blocks), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx);
-  else       hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), dim3(blocks), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx);
+  const dim3 grid(apply_blocks(s), N);
+  if (swish) hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx_add, dx);
+  else       hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx_add, dx);
   ODVAE_LAUNCH_CHECK("groupnorm bwd apply");
   return ODVAE_OK;
 }

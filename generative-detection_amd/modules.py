@@ -20,7 +20,11 @@ class Normalize(nn.GroupNorm):
     def __init__(self, channels, num_groups=32):
         super().__init__(num_groups=num_groups, num_channels=channels, eps=1e-6, affine=True)
 
-    def forward(self, x, swish=False):
+    def forward(self, x, swish=False, skip=False):
+        """skip=True also returns x for the block's skip connection; its gradient is then summed inside this node's
+        backward pass (ops.group_norm_skip)."""
+        if skip:
+            return ops.group_norm_skip(x, self.weight, self.bias, self.num_groups, self.eps, swish)
         return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, swish)
 
 
@@ -90,8 +94,8 @@ class ResnetBlock(nn.Module):
                 self.nin_shortcut = Conv1x1(in_channels, out_channels)
 
     def forward(self, x, temb=None):
-        h = self.conv1(self.norm1(x, swish=True))
-        h = self.norm2(h, swish=True)
+        h, x = self.norm1(x, swish=True, skip=True)
+        h = self.norm2(self.conv1(h), swish=True)
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
         return self.conv2(h, residual=x)  # x + h in the conv epilogue
@@ -108,7 +112,7 @@ class AttnBlock(nn.Module):
         self.proj_out = Conv1x1(in_channels, in_channels)
 
     def forward(self, x):
-        h = self.norm(x)
+        h, x = self.norm(x, skip=True)
         # one [C -> 3C] projection instead of three reads of h
         w = torch.cat([self.q.weight, self.k.weight, self.v.weight], dim=0)
         b = torch.cat([self.q.bias, self.k.bias, self.v.bias], dim=0)

@@ -347,7 +347,7 @@ def attention_qkv(qkv):
 # ------------------------------------------------------------------------------------------------------
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, swish):
+    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False):
         L = _L()
         x = _cl(x)
         n, c, h, w = x.shape
@@ -362,13 +362,20 @@ class _GroupNorm(Function):
                                              _lib.stream_ptr()), "groupnorm_fwd")
         ctx.groups, ctx.swish = groups, int(swish)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.set_materialize_grads(False)   # an unused output's gradient stays None instead of a tensor of zeros
+        if with_skip:
+            return y, x.view_as(x)   # the skip connection's handle on x: its gradient comes back into this node
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         L = _L()
         x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if dy is None:               # only the skip branch carried a gradient
+            return dskip, None, None, None, None, None, None
         dy = _cl(dy)
+        if dskip is not None:
+            dskip = _cl(dskip)
         n, c, h, w = x.shape
         dx = _new_cl(n, c, h, w, x)
         dg = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -378,12 +385,20 @@ class _GroupNorm(Function):
         wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, ctx.groups), x)
         _lib.check(L.odvae_groupnorm_bwd_f32(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(),
                                              b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(),
-                                             dg.data_ptr(), db.data_ptr(), wp, wn, _lib.stream_ptr()), "groupnorm_bwd")
-        return dx, dg, db, None, None, None
+                                             dg.data_ptr(), db.data_ptr(), _lib.ptr(dskip), wp, wn, _lib.stream_ptr()),
+                   "groupnorm_bwd")
+        return dx, dg, db, None, None, None, None
 
 
 def group_norm(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     return _GroupNorm.apply(x, gamma, beta, groups, eps, swish)
+
+
+def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
+    """(GroupNorm(x), x): the second output is x itself, to be used by the block's skip connection (`x + h`).  Its
+    gradient returns into this node and is summed into dx inside the GroupNorm backward pass (one pass instead of
+    autograd's separate 3-pass add)."""
+    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True)
 
 
 # ------------------------------------------------------------------------------------------------------

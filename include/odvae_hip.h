@@ -81,8 +81,10 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
                             void* workspace, size_t workspace_bytes, void* stream);
 int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
-                            float* dx, float* dgamma, float* dbeta,
+                            float* dx, float* dgamma, float* dbeta, const float* dx_add,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* dx_add (nullable, same shape as x): a second gradient reaching x (the ResnetBlock / AttnBlock skip connection,
+   [UPSTREAM] model.py `return x + h`), summed into dx in the same pass instead of autograd's separate add kernel */
 
 /* ---- elementwise.hip ------------------------------------------------------------------------------ */
 /* torch.nn.functional.softmax(scale * x, dim=-1) over rows (AttnBlock); y may alias x */

@@ -156,6 +156,30 @@ def test_groupnorm(hip_lib, n, c, h, w, swish):
     close(bd.grad, br.grad, BWD_TOL * 4, "gn dbeta")
 
 
+def test_group_norm_skip_sums_both_gradients(hip_lib):
+    """group_norm_skip hands x out a second time for the block's skip connection and folds that branch's gradient into
+    the GroupNorm backward pass: dx = dGN(dy) + dskip, exactly what autograd's separate add would produce."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    gamma, beta = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    gy, gs = torch.randn(2, 64, 8, 8, generator=g), torch.randn(2, 64, 8, 8, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.group_norm(xr, 32, gamma, beta, eps=1e-6)
+    (y_ref * torch.sigmoid(y_ref) * gy).sum().backward()
+    ref = xr.grad + gs
+    xd = x.to(dev()).requires_grad_(True)
+    y, xs = ops.group_norm_skip(xd, gamma.to(dev()), beta.to(dev()), 32, 1e-6, True)
+    assert xs.data_ptr() == xd.data_ptr() or torch.equal(xs, xd)
+    ((y * gy.to(dev())).sum() + (xs * gs.to(dev())).sum()).backward()
+    close(xd.grad, ref, BWD_TOL, "gn skip dx")
+    # the skip output alone (GroupNorm branch unused) still passes its gradient through
+    xd2 = x.to(dev()).requires_grad_(True)
+    _, xs2 = ops.group_norm_skip(xd2, gamma.to(dev()), beta.to(dev()), 32, 1e-6, True)
+    (xs2 * gs.to(dev())).sum().backward()
+    close(xd2.grad, gs, 1e-7, "gn skip only")
+
+
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 64, 8, 8), (1, 128, 128, 16, 16), (3, 32, 16, 4, 4), (2, 16, 16, 4, 4)])
 def test_conv1x1(hip_lib, n, cin, cout, h, w):
