@@ -5,6 +5,9 @@
 //   Downsample (F.pad(x,(0,1,0,1)) + conv stride 2 pad 0)            -> MODE 1
 //   Upsample (F.interpolate(scale 2, nearest) + conv stride 1 pad 1) -> MODE 2 (no 4x intermediate)
 //   data-gradient of MODE 1 (stride-2 transposed conv)               -> MODE 3
+//   Upsample + conv by output parity class (four 2x2-tap convs on the low-res input, pre-summed weights:
+//   16 instead of 36 tap-products per input pixel)                   -> MODE 5;  its data gradient, a 4x4-tap
+//   stride-2 pad-1 conv over dy with pre-summed weights             -> MODE 6   (v2 kernel only)
 // reached from src/modules/autoencodermodules/feat_encoder.py:4, feat_decoder.py:4 of the reference.
 // The data-gradient of MODE 0 is MODE 0 itself on weights packed with flipped taps and swapped
 // channel roles (odvae_conv3x3_pack_f32 makes both packs).
@@ -37,6 +40,8 @@ template <> struct Halo<0> { static constexpr int H = TH + 2, W = TW + 2; };
 template <> struct Halo<1> { static constexpr int H = 2 * TH + 1, W = 2 * TW + 1; };
 template <> struct Halo<2> { static constexpr int H = TH / 2 + 2, W = TW / 2 + 2; };
 template <> struct Halo<3> { static constexpr int H = TH / 2 + 1, W = TW / 2 + 1; };
+template <> struct Halo<5> { static constexpr int H = TH + 2, W = TW + 2; };          // tile = low-res pixels
+template <> struct Halo<6> { static constexpr int H = 2 * TH + 2, W = 2 * TW + 2; };  // halo over dy at 2x resolution
 
 // halo pixel index for output pixel (r,c) of the tile and tap (kh,kw); ok=false -> operand is zero
 template <int MODE>
@@ -54,6 +59,8 @@ template <int MODE>
 __device__ __forceinline__ void halo_origin(int oy0, int ox0, int& iy0, int& ix0) {
   if (MODE == 0) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
   else if (MODE == 1) { iy0 = 2 * oy0; ix0 = 2 * ox0; }
+  else if (MODE == 5) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
+  else if (MODE == 6) { iy0 = 2 * oy0 - 1; ix0 = 2 * ox0 - 1; }
   else { iy0 = oy0 / 2 - 1; ix0 = ox0 / 2 - 1; }
 }
 
@@ -242,11 +249,16 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
   constexpr int NG = KC / 8;
   constexpr int HALO_F4 = HPIX * QC;
   constexpr int HALO_IT = (HALO_F4 + 255) / 256;
+  constexpr int KW = MODE == 5 ? 2 : (MODE == 6 ? 4 : 3);   // taps per row; TAPS = KW * KW
+  constexpr int TAPS = KW * KW;
   __shared__ __attribute__((aligned(16))) float smem[2 * HPIX * HS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, h = lane >> 5;
+  // MODE 5: blockIdx.z = output parity class (py, px); the tile is 8x16 LOW-RES pixels and pixel (y, x) of it produces
+  // output pixel (2y + py, 2x + px) from input pixels (y + py - 1 + a, x + px - 1 + b), a, b in {0, 1}
+  const int cls = MODE == 5 ? (int)blockIdx.z : 0, py = cls >> 1, px = cls & 1;
 
   int t = blockIdx.x;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -283,6 +295,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
   auto pix_byte = [&](int mt, int r) -> unsigned {
     int pr, pc;
     tile_pixel(wm * WMT + mt, acc_row(r, lane), pr, pc);
+    if (MODE == 5) {
+      const int ly = oy0 + pr, lx = ox0 + pc;
+      return (ly < p.Hi && lx < p.Wi) ? (unsigned)(((2 * ly + py) * p.Wo + 2 * lx + px) * p.Cout) * 4u : OOB;
+    }
     const int oy = oy0 + pr, ox = ox0 + pc;
     return (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) * 4u : OOB;
   };
@@ -373,13 +389,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
 #pragma unroll
   for (int nt = 0; nt < WNT; ++nt) ncol[nt] = n0 + (wn * WNT + nt) * 32 + li;
   auto load_b = [&](int ch, int tap, int g, float4 (&b)[WNT]) {
-    const int64_t base = ((int64_t)tap * QT + ch * QC + 2 * g + h) * p.CoutP;
+    const int64_t base = ((int64_t)(cls * TAPS + tap) * QT + ch * QC + 2 * g + h) * p.CoutP;
 #pragma unroll
     for (int nt = 0; nt < WNT; ++nt) b[nt] = wq[base + ncol[nt]];
   };
 
   const int nchunks = p.CinP / KC;
-  constexpr int NIT = 9 * NG;   // (tap, k-group) steps per chunk, 16 MFMAs per wave each
+  constexpr int NIT = TAPS * NG;   // (tap, k-group) steps per chunk, 16 MFMAs per wave each
   float4 bc[WNT], bn[WNT], ac[WMT], an[WMT];
   // A fragment of step `it` of the current chunk: halo pixel of (tile pixel, tap), channels 8g + 4h .. +3
   auto load_a = [&](const float* Hs, int it, float4 (&a)[WMT]) {
@@ -388,8 +404,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_kernel_v2(ConvParams p) {
     for (int mt = 0; mt < WMT; ++mt) {
       int pr, pc;
       tile_pixel(wm * WMT + mt, li, pr, pc);
-      bool ok;
-      const int off = halo_index<MODE>(pr, pc, tap / 3, tap % 3, ok) * HS + 4 * h + 8 * g;
+      int hp;
+      if (MODE == 5) hp = (pr + py + tap / KW) * Halo<5>::W + (pc + px + tap % KW);
+      else if (MODE == 6) hp = (2 * pr + tap / KW) * Halo<6>::W + (2 * pc + tap % KW);
+      else { bool ok; hp = halo_index<(MODE <= 3 ? MODE : 0)>(pr, pc, tap / 3, tap % 3, ok); }
+      const int off = hp * HS + 4 * h + 8 * g;
       a[mt] = *reinterpret_cast<const float4*>(Hs + off);   // MODE 3: dead taps read a harmless in-range pixel
     }
   };
@@ -506,6 +525,49 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, int Cout, int C
   }
 }
 
+// Upsample (nearest 2x) + conv3x3 with the taps that hit the same low-res pixel pre-summed.
+// fwd16 [cls*4 + a*2 + b][CinP/4][CoutP][4], cls = 2*py + px: weight of input pixel (y + py - 1 + a, x + px - 1 + b) for output
+//   (2y + py, 2x + px) = sum of W[kh][kw] over kh in R(py, a), kw in R(px, b);  R(0,0)={0} R(0,1)={1,2} R(1,0)={0,1} R(1,1)={2}
+// dgr16 [u*4 + v][CoutP_d/4][CinP_d][4]: weight of dy pixel (2y + u - 1, 2x + v - 1) for dx (y, x) = sum of W[kh][kw] over
+//   kh in Q(u), kw in Q(v);  Q(0)={2} Q(1)={1,2} Q(2)={0,1} Q(3)={0}
+__device__ __forceinline__ float up_row_sum(const float* w9, int lo_h, int hi_h, int lo_w, int hi_w) {
+  float s = 0.f;
+  for (int kh = lo_h; kh <= hi_h; ++kh)
+    for (int kw = lo_w; kw <= hi_w; ++kw) s += w9[kh * 3 + kw];
+  return s;
+}
+__global__ void conv3x3_pack_up_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                       float* __restrict__ fwd, int CinP_f, int CoutP_f,
+                                       float* __restrict__ dgr, int CoutP_d, int CinP_d) {
+  const int64_t nf = fwd ? (int64_t)16 * CinP_f * CoutP_f : 0;
+  const int64_t nd = dgr ? (int64_t)16 * CoutP_d * CinP_d : 0;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx < nf) {
+      int64_t r = idx;
+      const int j = r & 3; r >>= 2;
+      const int co = (int)(r % CoutP_f); r /= CoutP_f;
+      const int q = (int)(r % (CinP_f / 4)); const int t16 = (int)(r / (CinP_f / 4));
+      const int ci = 4 * q + j;
+      const int cls = t16 >> 2, a = (t16 >> 1) & 1, b = t16 & 1, py = cls >> 1, px = cls & 1;
+      // R(p, t): p=0,t=0 -> {0}; p=0,t=1 -> {1,2}; p=1,t=0 -> {0,1}; p=1,t=1 -> {2}
+      const int lo_h = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), hi_h = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+      const int lo_w = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), hi_w = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+      fwd[idx] = (co < Cout && ci < Cin) ? up_row_sum(w + ((int64_t)co * Cin + ci) * 9, lo_h, hi_h, lo_w, hi_w) : 0.f;
+    } else {
+      int64_t r = idx - nf;
+      const int j = r & 3; r >>= 2;
+      const int ci = (int)(r % CinP_d); r /= CinP_d;
+      const int q = (int)(r % (CoutP_d / 4)); const int t16 = (int)(r / (CoutP_d / 4));
+      const int co = 4 * q + j;
+      const int u = t16 >> 2, v = t16 & 3;
+      const int lo_h = u == 0 ? 2 : (u == 1 ? 1 : 0), hi_h = u == 0 ? 2 : (u == 1 ? 2 : (u == 2 ? 1 : 0));
+      const int lo_w = v == 0 ? 2 : (v == 1 ? 1 : 0), hi_w = v == 0 ? 2 : (v == 1 ? 2 : (v == 2 ? 1 : 0));
+      dgr[idx - nf] = (co < Cout && ci < Cin) ? up_row_sum(w + ((int64_t)co * Cin + ci) * 9, lo_h, hi_h, lo_w, hi_w) : 0.f;
+    }
+  }
+}
+
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 }  // namespace
@@ -542,8 +604,28 @@ int odvae_conv3x3_pack_f32(const float* w, int Cout, int Cin, float* fwd_pack, f
   return ODVAE_OK;
 }
 
+// 16-tap packs of an Upsample conv (modes 5 / 6): fwd16 has 16 * reduce_pad(Cin) * out_pad(Cout) floats, dgrad16 has
+// 16 * reduce_pad(Cout) * out_pad(Cin) floats; either may be null
+size_t odvae_conv3x3_up_pack_floats(int c_reduce, int c_out) {
+  return (size_t)16 * odvae_conv3x3_pack_reduce_pad(c_reduce) * odvae_conv3x3_pack_out_pad(c_out);
+}
+int odvae_conv3x3_pack_up_f32(const float* w, int Cout, int Cin, float* fwd16, float* dgrad16, void* stream) {
+  ODVAE_CHECK_ARG(w && Cout > 0 && Cin > 0, "conv3x3_pack_up: bad arguments");
+  const int CinP_f = odvae_conv3x3_pack_reduce_pad(Cin), CoutP_f = odvae_conv3x3_pack_out_pad(Cout);
+  const int CoutP_d = odvae_conv3x3_pack_reduce_pad(Cout), CinP_d = odvae_conv3x3_pack_out_pad(Cin);
+  const int64_t total = (fwd16 ? (int64_t)16 * CinP_f * CoutP_f : 0) + (dgrad16 ? (int64_t)16 * CoutP_d * CinP_d : 0);
+  if (total == 0) return ODVAE_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 2048);
+  hipLaunchKernelGGL(conv3x3_pack_up_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w, Cout, Cin, fwd16, CinP_f, CoutP_f, dgrad16, CoutP_d, CinP_d);
+  ODVAE_LAUNCH_CHECK("conv3x3_pack_up");
+  return ODVAE_OK;
+}
+
 // y = act(conv3x3(x) (+bias) (+residual)), act: 0 none | 1 ReLU.  mode: 0 stride 1 pad 1 | 1 pad(0,1,0,1)+stride 2 |
-// 2 nearest-2x-upsample then stride 1 pad 1 | 3 transposed stride 2 (data gradient of mode 1).
+// 2 nearest-2x-upsample then stride 1 pad 1 | 3 transposed stride 2 (data gradient of mode 1) |
+// 5 = mode 2 computed per output parity class from a 16-tap pack (odvae_conv3x3_pack_up_f32 fwd16) |
+// 6 = data gradient of mode 2 / 5: x = dy [N][2Ho][2Wo][Cin], y = dx [N][Ho][Wo][Cout], wpk = dgrad16.
 // wpk: pack with reduction axis Cin and output axis Cout (for data gradients pass the dgrad pack,
 // Cin = channels of x (= dy), Cout = channels of y (= dx)).
 int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
@@ -551,10 +633,11 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
                       float* y, int Ho, int Wo, int act, void* stream) {
   ODVAE_CHECK_ARG(x && wpk && y, "conv3x3: null operand");
   ODVAE_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv3x3: empty shape");
-  ODVAE_CHECK_ARG(mode >= 0 && mode <= 3, "conv3x3: mode %d", mode);
+  ODVAE_CHECK_ARG((mode >= 0 && mode <= 3) || mode == 5 || mode == 6, "conv3x3: mode %d", mode);
   if (mode == 0) ODVAE_CHECK_ARG(Ho == Hi && Wo == Wi, "conv3x3 mode 0: Ho,Wo must equal Hi,Wi");
   if (mode == 1) ODVAE_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv3x3 mode 1: need even Hi,Wi and Ho=Hi/2");
-  if (mode == 2 || mode == 3) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3 mode %d: need Ho=2*Hi", mode);
+  if (mode == 2 || mode == 3 || mode == 5) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3 mode %d: need Ho=2*Hi", mode);
+  if (mode == 6) ODVAE_CHECK_ARG(Hi == 2 * Ho && Wi == 2 * Wo, "conv3x3 mode 6: need Hi=2*Ho");
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)wpk & 15) == 0, "conv3x3: x/wpk must be 16-byte aligned");
   ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 4 < 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * 4 < 0x7FFFFFF0ll,
                   "conv3x3: one input / output image must stay below 2 GiB");
@@ -563,7 +646,7 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   p.x = x; p.wpk = wpk; p.bias = bias; p.residual = residual; p.y = y;
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.CinP = odvae_conv3x3_pack_reduce_pad(Cin); p.CoutP = odvae_conv3x3_pack_out_pad(Cout);
-  p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, TH);
+  p.tiles_x = ceil_div(mode == 5 ? Wi : Wo, TW); p.tiles_y = ceil_div(mode == 5 ? Hi : Ho, TH);   // mode 5 tiles the low-res grid
   p.act = act;
   const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3: too many tiles");
@@ -572,7 +655,7 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   dim3 block(256);
   // ODVAE_CONV_V1=1 selects the round-1 per-tap-barrier kernel (kept for in-process A/B timing)
   static const int variant = getenv("ODVAE_CONV_VARIANT") ? atoi(getenv("ODVAE_CONV_VARIANT")) : 1;
-  const bool use_v1 = variant == 0;
+  const bool use_v1 = variant == 0 && mode <= 3;
 #define ODVAE_CONV_LAUNCH(KERNEL, MODE, KC)                                                                      \
   if (narrow) hipLaunchKernelGGL((KERNEL<MODE, KC, 1, 1, 4, 1>), dim3((unsigned)sp, p.CoutP / 32), block, 0, st, p); \
   else hipLaunchKernelGGL((KERNEL<MODE, KC, 2, 2, 2, 2>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p)
@@ -594,6 +677,11 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
         break;
       case 1: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 1, 8); break;
       case 2: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 2, 32); break;
+      case 5:
+        if (narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<5, 32, 1, 1, 4, 1>), dim3((unsigned)sp, p.CoutP / 32, 4), block, 0, st, p);
+        else hipLaunchKernelGGL((conv3x3_kernel_v2<5, 32, 2, 2, 2, 2>), dim3((unsigned)sp, p.CoutP / 128, 4), block, 0, st, p);
+        break;
+      case 6: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 6, 8); break;
       default: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 3, 32); break;
     }
   }

@@ -5,6 +5,7 @@ parameters (checkpoint interchange with the reference) and are r
 torch supplies device memory, the current stream and autograd bookkeeping; every FLOP and every byte
 of the hot path moves through libodvae_hip.so.  No CPU fallback exists.
 """
+import os
 import weakref
 
 import torch
@@ -101,13 +102,13 @@ class _PackCache:
     def bump(self):
         self.epoch += 1
 
-    def get(self, weight, want_dgrad):
-        key = id(weight)
+    def get(self, weight, want_dgrad, up=False):
+        key = (id(weight), up)
         tag = (weight.data_ptr(), weight._version, self.epoch)
         hit = self.store.get(key)
         if hit is not None and hit[0]() is weight and hit[1] == tag and (hit[3] is not None or not want_dgrad):
             return hit[2], hit[3]
-        fwd, dgr = _pack_conv3x3_now(weight, True, want_dgrad)
+        fwd, dgr = _pack_conv3x3_now(weight, True, want_dgrad, up)
         if len(self.store) > 4096:   # transient weights (tests): drop entries whose tensor is gone
             self.store = {k: v for k, v in self.store.items() if v[0]() is not None}
         self.store[key] = (weakref.ref(weight), tag, fwd, dgr)
@@ -117,25 +118,32 @@ class _PackCache:
 PACK_CACHE = _PackCache()
 
 
-def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False):
+def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False, up=False):
+    """up=True: the 16-tap packs of an Upsample conv (taps that hit the same low-res pixel pre-summed, modes 5 / 6)."""
     L = _L()
     w = weight.detach().contiguous()
     _lib.require_device(w)
     cout, cin = w.shape[0], w.shape[1]
+    floats = L.odvae_conv3x3_up_pack_floats if up else L.odvae_conv3x3_pack_floats
     fwd = dgr = None
     if want_fwd:
-        fwd = torch.empty(L.odvae_conv3x3_pack_floats(cin, cout), dtype=torch.float32, device=w.device)
+        fwd = torch.empty(floats(cin, cout), dtype=torch.float32, device=w.device)
     if want_dgrad:
-        dgr = torch.empty(L.odvae_conv3x3_pack_floats(cout, cin), dtype=torch.float32, device=w.device)
-    _lib.check(L.odvae_conv3x3_pack_f32(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()),
-               "conv3x3_pack")
+        dgr = torch.empty(floats(cout, cin), dtype=torch.float32, device=w.device)
+    pack = L.odvae_conv3x3_pack_up_f32 if up else L.odvae_conv3x3_pack_f32
+    _lib.check(pack(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv3x3_pack")
     return fwd, dgr
 
 
-def pack_conv3x3(weight, want_fwd=True, want_dgrad=False):
+def pack_conv3x3(weight, want_fwd=True, want_dgrad=False, up=False):
     """OIHW parameter -> kernel packs (see conv3x3_f32.hip), cached per weight update."""
-    fwd, dgr = PACK_CACHE.get(weight, want_dgrad)
+    fwd, dgr = PACK_CACHE.get(weight, want_dgrad, up)
     return (fwd if want_fwd else None), (dgr if want_dgrad else None)
+
+
+# Upsample + conv3x3: 1 = per output parity class with pre-summed taps (modes 5 / 6, 16 instead of 36 tap-products per
+# input pixel); ODVAE_UPCONV_DENSE=1 keeps the dense form (mode 2, data gradient = mode 0 + 2x2 sum-pool) for A/B runs
+UPCONV_BY_PARITY = os.environ.get("ODVAE_UPCONV_DENSE", "0") != "1"
 
 
 def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
@@ -143,7 +151,7 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
     n, _, hi, wi = x.shape
     if mode == 0:
         ho, wo = hi, wi
-    elif mode == 1:
+    elif mode in (1, 6):
         ho, wo = hi // 2, wi // 2
     else:
         ho, wo = 2 * hi, 2 * wi
@@ -165,10 +173,11 @@ class _Conv3x3(Function):
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
-        fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]))  # both packs in one launch
+        up = mode == 2 and UPCONV_BY_PARITY
+        fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), up)  # both packs in one launch
         b = bias.detach().contiguous() if bias is not None else None
-        y = _conv3x3_raw(mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
-        ctx.mode = mode
+        y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
+        ctx.mode, ctx.up = mode, up
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -191,11 +200,13 @@ class _Conv3x3(Function):
         _, _, ho, wo = dy.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            _, dgr = pack_conv3x3(weight, False, True)
+            _, dgr = pack_conv3x3(weight, False, True, ctx.up)
             if mode == 0:
                 dx = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)
             elif mode == 1:
                 dx = _conv3x3_raw(3, dy, dgr, cout, cin, None, None)
+            elif ctx.up:
+                dx = _conv3x3_raw(6, dy, dgr, cout, cin, None, None)   # 4x4-tap stride-2 conv over dy, pre-summed weights
             else:
                 du = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)  # gradient w.r.t. the upsampled image
                 dx = _new_cl(n, cin, hi, wi, x)

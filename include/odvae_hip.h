@@ -57,10 +57,16 @@ int odvae_conv3x3_pack_reduce_pad(int c_reduce);
 int odvae_conv3x3_pack_out_pad(int c_out);
 size_t odvae_conv3x3_pack_floats(int c_reduce, int c_out);
 int odvae_conv3x3_pack_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
+/* 16-tap packs of an Upsample conv (modes 5 / 6): odvae_conv3x3_up_pack_floats(c_reduce, c_out) floats each */
+size_t odvae_conv3x3_up_pack_floats(int c_reduce, int c_out);
+int odvae_conv3x3_pack_up_f32(const float* w_oihw, int Cout, int Cin, float* fwd16, float* dgrad16, void* stream);
 /* mode 0: stride 1 pad 1 (ResnetBlock.conv1/conv2, conv_in, conv_out)
  * mode 1: F.pad(x,(0,1,0,1)) + stride 2 pad 0 (Downsample.forward)      Ho = Hi/2
  * mode 2: F.interpolate(scale 2, nearest) + stride 1 pad 1 (Upsample)   Ho = 2*Hi
  * mode 3: data gradient of mode 1 (x = dy, y = dx, wpk = dgrad pack)    Ho = 2*Hi
+ * mode 5: mode 2 evaluated per output parity class on the low-res input with the taps that hit the same input pixel
+ *         pre-summed (wpk = fwd16 of odvae_conv3x3_pack_up_f32; 16 instead of 36 tap-products per input pixel)  Ho = 2*Hi
+ * mode 6: data gradient of mode 2 / 5 = 4x4-tap stride-2 pad-1 conv over dy (x = dy, y = dx, wpk = dgrad16)   Ho = Hi/2
  * The data gradient of mode 0 is mode 0 with the dgrad pack. */
 int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
                       const float* wpk, int Cout, const float* bias, const float* residual,

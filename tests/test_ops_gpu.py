@@ -90,6 +90,9 @@ CONV_CASES = [
     (1, 1, 128, 128, 8, 8),
     (2, 2, 32, 32, 8, 16),
     (2, 1, 128, 128, 4, 4),
+    (2, 2, 64, 160, 11, 21),    # ragged tiles, Cout not a multiple of 128
+    (2, 1, 40, 24, 9, 5),       # narrow Cout (32-wide tile), Cin padded to 64
+    (2, 1, 256, 256, 16, 16),
 ]
 
 
@@ -121,6 +124,13 @@ def test_conv3x3_fwd_bwd(hip_lib, mode, n, cin, cout, h, w):
     close(wd.grad, wr.grad, BWD_TOL * math.sqrt(n * h * w / 64), "conv dw")
     close(bd.grad, br.grad, BWD_TOL * math.sqrt(n * h * w / 64), "conv db")
     close(resd.grad, resr.grad, 1e-6, "conv dres")
+
+
+def test_upsample_conv_dense_form_still_matches(hip_lib, monkeypatch):
+    """ODVAE_UPCONV_DENSE=1 keeps mode 2 (dense 3x3 at 2x resolution; data gradient = mode 0 + 2x2 sum-pool) for A/B."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "UPCONV_BY_PARITY", False)
+    test_conv3x3_fwd_bwd(hip_lib, 2, 2, 64, 160, 11, 21)
 
 
 def test_conv3x3_no_bias_no_res(hip_lib):
