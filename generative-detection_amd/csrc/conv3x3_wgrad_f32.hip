@@ -324,13 +324,200 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, cons
   }
 }
 
-struct Plan { int v2, th, tiles_x, tiles_y, ntiles, nsplit, tiles_per_split, CinP, CoutP, ci_tiles, co_tiles; };
+// ---- Upsample conv (nearest 2x + 3x3) by output parity class ---------------------------------------------------
+// dWeff[cls][a][b] = sum over low-res pixels (y, x) of x[y + py - 1 + a][x + px - 1 + b]^T dy[2y + py][2x + px], cls = 2 py + px:
+// 16 tap-products per low-res pixel instead of the 36 of the dense form (the forward pass multiplies the same
+// pre-summed weights, conv3x3_f32.hip mode 5); dW[kh][kw] is the sum of the four dWeff entries whose pre-sum contains
+// W[kh][kw].  Block = 64 ci x 64 co, 8 waves = 4 classes x 2 co sub-tiles, each wave both ci sub-tiles x 4 taps
+// (128 accumulator registers); pixel tile = 2 x 16 low-res pixels: halo [4 x 18][64 ci] and the four parity planes of
+// the 4 x 32 dy patch [cls][32 px][64 co] arrive by LDS-DMA, double-buffered, one barrier per tile.
+constexpr int UP_TH = 2, UP_BC = 64;
+struct UpGeom {
+  static constexpr int HALO_W = TW + 2, HPIX = (UP_TH + 2) * HALO_W;   // 72
+  static constexpr int NPIX = UP_TH * TW;                             // 32 low-res pixels
+  static constexpr int NH = (HPIX * (UP_BC / 4) + 63) / 64;           // 1 KiB pieces of the halo image
+  static constexpr int ND = 4 * NPIX * (UP_BC / 4) / 64;              // 1 KiB pieces of the dy planes
+  static constexpr int XS_F = NH * 256;
+  static constexpr int BUF_F = XS_F + 4 * NPIX * UP_BC;
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_up_kernel(WgradParams p) {
+  using G = UpGeom;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 * BUF_F floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cls = wave >> 1, wn = wave & 1, py = cls >> 1, px = cls & 1;
+  const int li = lane & 31, h = lane >> 5;
+  const int split = blockIdx.x;
+  const int ci_tile = blockIdx.y % p.ci_tiles, co_tile = blockIdx.y / p.ci_tiles;
+  const int ci0 = ci_tile * UP_BC, co0 = co_tile * UP_BC;
+  const bool do_bias = p.bslab != nullptr && ci_tile == 0;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
+  float bsum = 0.f;
+
+  auto issue = [&](int tile, int buf) {
+    int t = tile;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+    const int ly0 = ty * UP_TH, lx0 = tx * TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin), 0, p.Hi * p.Wi * p.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy + (int64_t)n * p.Ho * p.Wo * p.Cout), 0, p.Ho * p.Wo * p.Cout * 4, 0x00020000);
+    float* base = smem + buf * G::BUF_F;
+    const unsigned OOB = 0x7FFFFFF0u;   // >= num_records: the load returns 0
+    for (int j = wave; j < G::NH + G::ND; j += 8) {
+      if (j < G::NH) {
+        const int f = j * 64 + lane;
+        const int hp = f >> 4, q = f & 15;
+        const int iy = ly0 - 1 + hp / G::HALO_W, ix = lx0 - 1 + hp % G::HALO_W;
+        const int c = ci0 + 4 * q;
+        const bool ok = hp < G::HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin;
+        const unsigned voff = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + c) * 4) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + j * 256), 16, voff, 0, 0, 0);
+      } else {
+        const int jj = j - G::NH;
+        const int f = jj * 64 + lane;
+        const int pp = f >> 4, q = f & 15;              // pp = plane * 32 + low-res pixel of the tile
+        const int plane = pp >> 5, pl = pp & 31;
+        const int oy = 2 * (ly0 + pl / TW) + (plane >> 1), ox = 2 * (lx0 + pl % TW) + (plane & 1);
+        const int c = co0 + 4 * q;
+        const bool ok = oy < p.Ho && ox < p.Wo && c < p.Cout;
+        const unsigned voff = ok ? (unsigned)(((oy * p.Wo + ox) * p.Cout + c) * 4) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(base + G::XS_F + jj * 256), 16, voff, 0, 0, 0);
+      }
+    }
+  };
+
+  const int t_beg = split * p.tiles_per_split;
+  const int ntl = min(p.ntiles, t_beg + p.tiles_per_split) - t_beg;
+  if (ntl > 0) issue(t_beg, 0);
+  for (int it = 0; it < ntl; ++it) {
+    const int cur = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` have landed
+    __syncthreads();                                    // everyone's have; buffer cur^1 is free again
+    if (it + 1 < ntl) issue(t_beg + it + 1, cur ^ 1);
+    // lane half h takes low-res pixel 2s+h of k-step s (same tile row: TW is even); the class offset is wave-uniform
+    const float* xa = smem + cur * G::BUF_F + ((py * G::HALO_W + px) + h) * UP_BC + li;                 // [HPIX][64]
+    const float* db = smem + cur * G::BUF_F + G::XS_F + (cls * G::NPIX + h) * UP_BC + wn * 32 + li;     // [4][32][64]
+    auto load_step = [&](int s, float (&a)[2][4], float& b) {
+      const int r = (2 * s) / TW, c = (2 * s) % TW;   // compile-time after unrolling
+      b = db[2 * s * UP_BC];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt][t] = xa[((r + t / 2) * G::HALO_W + c + t % 2) * UP_BC + mt * 32];
+    };
+    float ac[2][4], an[2][4], bc, bn = 0.f;
+    load_step(0, ac, bc);
+#pragma unroll
+    for (int s = 0; s < G::NPIX / 2; ++s) {
+      if (s + 1 < G::NPIX / 2) load_step(s + 1, an, bn);
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += bc;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][t] = mfma32(ac[mt][t], bc, acc[mt][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      bc = bn;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ac[mt][t] = an[mt][t];
+    }
+  }
+
+  // slab [split][cls * 4 + tap][CinP][CoutP]
+  const int co = co0 + wn * 32 + li;
+  float* sl = p.slab + (int64_t)split * 16 * p.CinP * p.CoutP;
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(sl, 0, 16 * p.CinP * p.CoutP * 4, 0x00020000);
+  const int tap_stride = p.CinP * p.CoutP * 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned rowoff = (unsigned)((ci0 + mt * 32 + acc_row(r, lane)) * p.CoutP + co) * 4u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][t][r]), srsrc, rowoff, (cls * 4 + t) * tap_stride, 0);
+    }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0) p.bslab[((int64_t)split * 4 + cls) * p.CoutP + co] = bsum;
+  }
+}
+
+// dW[kh][kw] = sum of the dWeff entries (py, a) x (px, b) with kh in R(py, a), kw in R(px, b):
+// kh = 0: (0,0) (1,0) | kh = 1: (0,1) (1,0) | kh = 2: (0,1) (1,1); splits summed in a fixed order
+__global__ void conv3x3_wgrad_up_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                               int nsplit, int Cin, int Cout, int CinP, int CoutP,
+                                               float* __restrict__ dw, float* __restrict__ dbias) {
+  const int64_t mat = (int64_t)CinP * CoutP;
+  const int64_t per = 9 * mat;
+  const int64_t total = per + (dbias ? CoutP : 0);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    if (idx < per) {
+      const int co = (int)(idx % CoutP);
+      const int ci = (int)((idx / CoutP) % CinP);
+      const int tap = (int)(idx / mat);
+      if (co < Cout && ci < Cin) {
+        const int kh = tap / 3, kw = tap % 3;
+        const int pa[2][2] = {{0, kh == 0 ? 0 : 1}, {1, kh == 2 ? 1 : 0}};   // (py, a) pairs for kh
+        const int pb[2][2] = {{0, kw == 0 ? 0 : 1}, {1, kw == 2 ? 1 : 0}};   // (px, b) pairs for kw
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int t16 = (pa[i][0] * 2 + pb[j][0]) * 4 + pa[i][1] * 2 + pb[j][1];
+              s += slab[((int64_t)sp * 16 + t16) * mat + (int64_t)ci * CoutP + co];
+            }
+        dw[((int64_t)co * Cin + ci) * 9 + tap] = s;
+      }
+    } else {
+      const int co = (int)(idx - per);
+      if (co < Cout) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit * 4; ++sp) s += bslab[(int64_t)sp * CoutP + co];
+        dbias[co] = s;
+      }
+    }
+  }
+}
+
+struct Plan { int v2, up, th, tiles_x, tiles_y, ntiles, nsplit, tiles_per_split, CinP, CoutP, ci_tiles, co_tiles; };
 
 // v2 (LDS-DMA) whenever both channel counts allow 16-byte pieces and the 128-wide co tile is not mostly padding;
 // ODVAE_WGRAD_V1=1 forces the register-staged kernel (in-process A/B)
 Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
   static const bool force_v1 = getenv("ODVAE_WGRAD_V1") != nullptr;
   Plan pl;
+  pl.up = mode == 5 && !force_v1 && Cin % 4 == 0 && Cout % 4 == 0;
+  if (pl.up) {   // tiles of 2 x 16 LOW-RES pixels (Ho, Wo are the output's: twice the input's)
+    pl.v2 = 1; pl.th = UP_TH;
+    pl.tiles_x = ceil_div(Wo / 2, TW); pl.tiles_y = ceil_div(Ho / 2, UP_TH);
+    pl.ntiles = pl.tiles_x * pl.tiles_y * N;
+    pl.CinP = ceil_div(Cin, UP_BC) * UP_BC; pl.CoutP = ceil_div(Cout, UP_BC) * UP_BC;
+    pl.ci_tiles = pl.CinP / UP_BC; pl.co_tiles = pl.CoutP / UP_BC;
+    int nsplit = ceil_div(512, pl.ci_tiles * pl.co_tiles);
+    if (nsplit > pl.ntiles) nsplit = pl.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    pl.tiles_per_split = ceil_div(pl.ntiles, nsplit);
+    pl.nsplit = ceil_div(pl.ntiles, pl.tiles_per_split);
+    return pl;
+  }
+  if (mode == 5) mode = 2;   // channel counts the DMA kernel cannot take: dense form
   pl.v2 = !force_v1 && Cin % 4 == 0 && Cout % 4 == 0 && Cout > 64;
   const int bci = pl.v2 ? BCI2 : BC, bco = pl.v2 ? BCO2 : BC;
   pl.th = pl.v2 ? (mode == 1 ? 2 : 4) : (mode == 1 ? 4 : 8);
@@ -367,6 +554,7 @@ extern "C" {
 
 size_t odvae_conv3x3_wgrad_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
   const Plan pl = make_plan(mode, N, Ho, Wo, Cin, Cout);
+  if (pl.up) return ((size_t)pl.nsplit * 16 * pl.CinP * pl.CoutP + (size_t)pl.nsplit * 4 * pl.CoutP) * sizeof(float);
   return ((size_t)pl.nsplit * 9 * pl.CinP * pl.CoutP + (size_t)pl.nsplit * pl.CoutP) * sizeof(float);
 }
 
@@ -375,11 +563,11 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
                             int Ho, int Wo, int Cout, float* dw, float* dbias,
                             void* workspace, size_t workspace_bytes, void* stream) {
   ODVAE_CHECK_ARG(x && dy && dw, "conv3x3_wgrad: null operand");
-  ODVAE_CHECK_ARG(mode >= 0 && mode <= 2, "conv3x3_wgrad: mode %d", mode);
+  ODVAE_CHECK_ARG((mode >= 0 && mode <= 2) || mode == 5, "conv3x3_wgrad: mode %d", mode);
   ODVAE_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: empty shape");
   if (mode == 0) ODVAE_CHECK_ARG(Ho == Hi && Wo == Wi, "conv3x3_wgrad mode 0: Ho,Wo must equal Hi,Wi");
   if (mode == 1) ODVAE_CHECK_ARG(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv3x3_wgrad mode 1: need even Hi,Wi");
-  if (mode == 2) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3_wgrad mode 2: need Ho=2*Hi");
+  if (mode == 2 || mode == 5) ODVAE_CHECK_ARG(Ho == 2 * Hi && Wo == 2 * Wi, "conv3x3_wgrad mode %d: need Ho=2*Hi", mode);
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv3x3_wgrad: x/dy must be 16-byte aligned");
   ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 4 < 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * 4 < 0x7FFFFFF0ll, "conv3x3_wgrad: one image must stay below 2 GiB");
   const Plan pl = make_plan(mode, N, Ho, Wo, Cin, Cout);
@@ -391,7 +579,8 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
   WgradParams p;
   p.x = x; p.dy = dy;
   p.slab = static_cast<float*>(workspace);
-  p.bslab = dbias ? p.slab + (size_t)pl.nsplit * 9 * pl.CinP * pl.CoutP : nullptr;
+  p.bslab = dbias ? p.slab + (size_t)pl.nsplit * (pl.up ? 16 : 9) * pl.CinP * pl.CoutP : nullptr;
+  if (mode == 5 && !pl.up) mode = 2;
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.CinP = pl.CinP; p.CoutP = pl.CoutP;
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
@@ -399,6 +588,19 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(pl.nsplit, pl.ci_tiles * pl.co_tiles);
   hipError_t e = hipSuccess;
+  if (pl.up) {
+    e = launch_dyn(conv3x3_wgrad_up_kernel, grid, dim3(512), (size_t)2 * UpGeom::BUF_F * sizeof(float), st, p);
+    if (e != hipSuccess) {
+      odvae_set_error("conv3x3_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return ODVAE_ERR_HIP;
+    }
+    ODVAE_LAUNCH_CHECK("conv3x3_wgrad up");
+    const int64_t total = (int64_t)9 * pl.CinP * pl.CoutP + pl.CoutP;
+    hipLaunchKernelGGL(conv3x3_wgrad_up_reduce_kernel, dim3((int)std::min<int64_t>(ceil_div64(total, 256), 4096)), dim3(256), 0, st,
+                       p.slab, p.bslab, pl.nsplit, Cin, Cout, pl.CinP, pl.CoutP, dw, dbias);
+    ODVAE_LAUNCH_CHECK("conv3x3_wgrad up reduce");
+    return ODVAE_OK;
+  }
   if (pl.v2) {
     if (mode == 0)      e = launch_dyn(conv3x3_wgrad_dma_kernel<0, 4>, grid, dim3(512), (size_t)2 * DmaGeom<0, 4>::BUF_F * sizeof(float), st, p);
     else if (mode == 1) e = launch_dyn(conv3x3_wgrad_dma_kernel<1, 2>, grid, dim3(512), (size_t)2 * DmaGeom<1, 2>::BUF_F * sizeof(float), st, p);

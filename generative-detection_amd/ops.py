@@ -215,11 +215,12 @@ class _Conv3x3(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            need = L.odvae_conv3x3_wgrad_workspace_bytes(mode, n, ho, wo, cin, cout)
+            wmode = 5 if ctx.up else mode
+            need = L.odvae_conv3x3_wgrad_workspace_bytes(wmode, n, ho, wo, cin, cout)
             wp, wn = _ws(need, x)
-            _lib.check(L.odvae_conv3x3_wgrad_f32(mode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,
+            _lib.check(L.odvae_conv3x3_wgrad_f32(wmode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,
                                                  dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
-                       "conv3x3_wgrad(mode=%d)" % mode)
+                       "conv3x3_wgrad(mode=%d)" % wmode)
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None
 

@@ -72,7 +72,8 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
                       const float* wpk, int Cout, const float* bias, const float* residual,
                       float* y, int Ho, int Wo, int act /* 0 none, 1 ReLU */, void* stream);
 
-/* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2)
+/* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
+ * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)
  * dw is OIHW [Cout][Cin][3][3], overwritten; dbias [Cout] or NULL. */
 size_t odvae_conv3x3_wgrad_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout);
 int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, int Hi, int Wi, int Cin,
