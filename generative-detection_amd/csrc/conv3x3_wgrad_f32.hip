@@ -496,6 +496,127 @@ __global__ void conv3x3_wgrad_up_reduce_kernel(const float* __restrict__ slab, c
   }
 }
 
+// ---- thin side: conv_in (3 -> C) and conv_out (C -> 3) ----------------------------------------------------------
+// With <= 3 channels on one side the nine taps of that side fit ONE 32-wide MFMA operand: out[c][j] = sum over pixels
+// of big[pixel][c] * small[pixel shifted by tap(j)][cs(j)], j = tap * Cs + cs < 27 -- a [C x pixels] x [pixels x 32]
+// product that reads the wide tensor exactly once (HBM-bound: 1 GiB at 128 ch, 256^2, B=32).
+//   conv_in : big = dy, small = x read at (y + kh - 1, x + kw - 1); column 27 multiplies 1.0, i.e. the bias gradient
+//   conv_out: big = x,  small = dy read at (y - kh + 1, x - kw + 1)   (the same sum re-indexed by the input pixel)
+// No LDS, no barriers: A fragments are coalesced 128-byte channel rows, B fragments gathers from the 25 MB tensor (cache
+// resident); a wave owns whole image rows, eight k-steps (16 pixels) of loads in flight behind eight steps of MFMAs.
+struct ThinParams {
+  const float* big;     // [N][H][W][Cb]
+  const float* small;   // [N][H][W][Cs]
+  float* slab;          // [waves][CbP][32]
+  int N, H, W, Cb, Cs, CbP, sign, ones_col;   // ones_col: column index that multiplies 1.0 (bias gradient), or -1
+};
+
+template <int CT>   // 32-channel tiles per wave
+__global__ __launch_bounds__(256) void conv3x3_wgrad_thin_kernel(ThinParams p) {
+  const int lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
+  const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int c0 = blockIdx.y * CT * 32;
+  // this lane's B column: tap and channel of the thin side
+  const int j = li, tap = j / p.Cs, cs = j % p.Cs;
+  const bool jtap = j < 9 * p.Cs;
+  const int dyj = p.sign * (tap / 3 - 1), dxj = p.sign * (tap % 3 - 1);
+  const bool ones = j == p.ones_col;
+  // channel tiles past Cb (Cb not a multiple of 128): clamped address + select, never a guarded load
+  int coff[CT];
+  bool cok[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    cok[ct] = c0 + ct * 32 + li < p.Cb;
+    coff[ct] = min(c0 + ct * 32 + li, p.Cb - 1);
+  }
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const int rows = p.N * p.H;
+  constexpr int CH = 8;   // k-steps per chunk (16 pixels)
+  float a_cur[CH][CT], b_cur[CH], a_nxt[CH][CT], b_nxt[CH];
+  for (int row = wave_in_grid; row < rows; row += nwaves) {
+    const int y = row % p.H;
+    const int ys = y + dyj;
+    const bool rowok = jtap && ys >= 0 && ys < p.H;
+    const float* srow = p.small + ((int64_t)(row - y + min(max(ys, 0), p.H - 1)) * p.W) * p.Cs + cs;
+    const int64_t brow = (int64_t)row * p.W * p.Cb;
+    auto load_chunk = [&](int x0, float (&a)[CH][CT], float (&b)[CH]) {
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const int x = x0 + 2 * s + kk;
+        const float* ap = p.big + brow + (int64_t)x * p.Cb;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { const float v = ap[coff[ct]]; a[s][ct] = cok[ct] ? v : 0.f; }
+        const int xs = x + dxj;
+        const float v = srow[(int64_t)min(max(xs, 0), p.W - 1) * p.Cs];
+        b[s] = ones ? 1.f : ((rowok && xs >= 0 && xs < p.W) ? v : 0.f);
+      }
+    };
+    load_chunk(0, a_cur, b_cur);
+    for (int x0 = 0; x0 < p.W; x0 += 2 * CH) {
+      if (x0 + 2 * CH < p.W) load_chunk(x0 + 2 * CH, a_nxt, b_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < CH; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma32(a_cur[s][ct], b_cur[s], acc[ct]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        b_cur[s] = b_nxt[s];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) a_cur[s][ct] = a_nxt[s][ct];
+      }
+    }
+  }
+  float* sl = p.slab + (int64_t)wave_in_grid * p.CbP * 32;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + ct * 32 + acc_row(r, lane);
+      if (c < p.Cb) sl[c * 32 + li] = acc[ct][r];
+    }
+}
+
+// partial column sums of the thin tensor (bias gradient of conv_out): part[block][Cs]
+__global__ __launch_bounds__(256) void thin_colsum_kernel(const float* __restrict__ t, int64_t npix, int Cs, float* __restrict__ part) {
+  __shared__ float red[4][3];
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x; px < npix; px += (int64_t)gridDim.x * 256)
+    for (int c = 0; c < Cs; ++c) s[c] += t[px * Cs + c];
+  for (int c = 0; c < 3; ++c) s[c] = wave_sum(s[c]);
+  if ((threadIdx.x & 63) == 0) for (int c = 0; c < 3; ++c) red[threadIdx.x >> 6][c] = s[c];
+  __syncthreads();
+  if (threadIdx.x < Cs) part[blockIdx.x * Cs + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// sum the per-wave slabs in a fixed order and scatter into OIHW; sign +1: c = co, thin = ci; sign -1: c = ci, thin = co
+__global__ void conv3x3_wgrad_thin_reduce_kernel(const float* __restrict__ slab, int nwaves, int Cb, int Cs, int CbP, int sign,
+                                                 const float* __restrict__ bpart, int nbpart, int Cin, int Cout,
+                                                 float* __restrict__ dw, float* __restrict__ dbias) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < Cb * 32) {
+    const int c = idx / 32, j = idx % 32;
+    float s = 0.f;
+    for (int w = 0; w < nwaves; ++w) s += slab[((int64_t)w * CbP + c) * 32 + j];
+    if (j < 9 * Cs) {
+      const int tap = j / Cs, cs = j % Cs;
+      const int co = sign > 0 ? c : cs, ci = sign > 0 ? cs : c;
+      dw[((int64_t)co * Cin + ci) * 9 + tap] = s;
+    } else if (sign > 0 && dbias && j == 9 * Cs) dbias[c] = s;
+  } else if (sign < 0 && dbias && idx - Cb * 32 < Cout) {
+    const int co = idx - Cb * 32;
+    float s = 0.f;
+    for (int b = 0; b < nbpart; ++b) s += bpart[b * Cs + co];
+    dbias[co] = s;
+  }
+}
+
 struct Plan { int v2, up, th, tiles_x, tiles_y, ntiles, nsplit, tiles_per_split, CinP, CoutP, ci_tiles, co_tiles; };
 
 // v2 (LDS-DMA) whenever both channel counts allow 16-byte pieces and the 128-wide co tile is not mostly padding;
@@ -537,6 +658,19 @@ Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
   return pl;
 }
 
+// thin-side kernel: stride-1 conv whose input or output has <= 3 channels (conv_in / conv_out)
+constexpr int THIN_BLOCKS = 512, THIN_BIAS_BLOCKS = 256;
+bool thin_applies(int mode, int Hi, int Wi, int Cin, int Cout) {
+  static const bool off = getenv("ODVAE_WGRAD_V1") != nullptr;
+  const int cb = Cin <= 3 ? Cout : Cin;
+  return !off && mode == 0 && (Cin <= 3) != (Cout <= 3) && Wi % 16 == 0 && cb % 32 == 0 &&
+         (int64_t)Hi * Wi * cb * 4 < 0x7FFFFFF0ll;
+}
+size_t thin_workspace_floats(int Cin, int Cout) {
+  const int cb = Cin <= 3 ? Cout : Cin;
+  return (size_t)THIN_BLOCKS * 4 * cb * 32 + (size_t)THIN_BIAS_BLOCKS * 3;
+}
+
 template <int MODE, int TH>
 size_t wgrad_smem_bytes() { return (size_t)(Halo<MODE, TH>::H * Halo<MODE, TH>::W + TH * TW) * BC * sizeof(float); }
 
@@ -553,6 +687,7 @@ hipError_t launch_dyn(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t 
 extern "C" {
 
 size_t odvae_conv3x3_wgrad_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
+  if (thin_applies(mode, Ho, Wo, Cin, Cout)) return thin_workspace_floats(Cin, Cout) * sizeof(float);
   const Plan pl = make_plan(mode, N, Ho, Wo, Cin, Cout);
   if (pl.up) return ((size_t)pl.nsplit * 16 * pl.CinP * pl.CoutP + (size_t)pl.nsplit * 4 * pl.CoutP) * sizeof(float);
   return ((size_t)pl.nsplit * 9 * pl.CinP * pl.CoutP + (size_t)pl.nsplit * pl.CoutP) * sizeof(float);
@@ -576,6 +711,29 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
     odvae_set_error("conv3x3_wgrad: needs %zu workspace bytes, got %zu", need, workspace_bytes);
     return ODVAE_ERR_WORKSPACE;
   }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (thin_applies(mode, Hi, Wi, Cin, Cout)) {
+    ThinParams t;
+    const bool in_thin = Cin <= 3;   // conv_in: big = dy, small = x; conv_out: big = x, small = dy
+    t.big = in_thin ? dy : x; t.small = in_thin ? x : dy;
+    t.slab = static_cast<float*>(workspace);
+    t.N = N; t.H = Hi; t.W = Wi; t.Cb = in_thin ? Cout : Cin; t.Cs = in_thin ? Cin : Cout; t.CbP = t.Cb;
+    t.sign = in_thin ? 1 : -1; t.ones_col = (in_thin && dbias) ? 9 * t.Cs : -1;
+    const int groups = ceil_div(t.Cb, 128);
+    const int blocks = std::max(1, std::min(THIN_BLOCKS / groups, ceil_div(N * Hi, 4)));
+    hipLaunchKernelGGL((conv3x3_wgrad_thin_kernel<4>), dim3(blocks, groups), dim3(256), 0, st, t);
+    ODVAE_LAUNCH_CHECK("conv3x3_wgrad thin");
+    float* bpart = t.slab + (size_t)THIN_BLOCKS * 4 * t.Cb * 32;
+    if (!in_thin && dbias) {
+      hipLaunchKernelGGL(thin_colsum_kernel, dim3(THIN_BIAS_BLOCKS), dim3(256), 0, st, dy, (int64_t)N * Hi * Wi, Cout, bpart);
+      ODVAE_LAUNCH_CHECK("conv3x3_wgrad thin bias");
+    }
+    const int items = t.Cb * 32 + (in_thin ? 0 : Cout);
+    hipLaunchKernelGGL(conv3x3_wgrad_thin_reduce_kernel, dim3(ceil_div(items, 256)), dim3(256), 0, st,
+                       t.slab, blocks * 4, t.Cb, t.Cs, t.CbP, t.sign, bpart, THIN_BIAS_BLOCKS, Cin, Cout, dw, dbias);
+    ODVAE_LAUNCH_CHECK("conv3x3_wgrad thin reduce");
+    return ODVAE_OK;
+  }
   WgradParams p;
   p.x = x; p.dy = dy;
   p.slab = static_cast<float*>(workspace);
@@ -585,7 +743,6 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
   p.CinP = pl.CinP; p.CoutP = pl.CoutP;
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles;
   p.tiles_per_split = pl.tiles_per_split; p.ci_tiles = pl.ci_tiles;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(pl.nsplit, pl.ci_tiles * pl.co_tiles);
   hipError_t e = hipSuccess;
   if (pl.up) {

@@ -86,6 +86,9 @@ CONV_CASES = [
     (0, 2, 16, 32, 4, 4),
     (0, 1, 64, 160, 20, 12),
     (0, 1, 256, 256, 8, 8),
+    (0, 2, 3, 160, 8, 48),      # thin-side weight gradient, channel tiles past Cb
+    (0, 1, 160, 2, 12, 16),     # thin output side with 2 channels
+    (0, 3, 1, 64, 5, 16),       # thin input side with 1 channel
     (1, 2, 32, 32, 16, 32),
     (1, 1, 128, 128, 8, 8),
     (2, 2, 32, 32, 8, 16),
