@@ -511,46 +511,42 @@ struct ThinParams {
   int N, H, W, Cb, Cs, CbP, sign, ones_col;   // ones_col: column index that multiplies 1.0 (bias gradient), or -1
 };
 
-template <int CT>   // 32-channel tiles per wave
+// One 16-byte load per lane is a pixel's channels 4i..4i+3: component t feeds channel tile t, whose row i is therefore
+// channel c0 + 4i + t (any channel order will do, the slab store undoes it) -- a wave reads whole 512-byte pixel rows.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_kernel(ThinParams p) {
   const int lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
   const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  const int c0 = blockIdx.y * CT * 32;
+  const int c0 = blockIdx.y * 128;
   // this lane's B column: tap and channel of the thin side
   const int j = li, tap = j / p.Cs, cs = j % p.Cs;
   const bool jtap = j < 9 * p.Cs;
   const int dyj = p.sign * (tap / 3 - 1), dxj = p.sign * (tap % 3 - 1);
   const bool ones = j == p.ones_col;
-  // channel tiles past Cb (Cb not a multiple of 128): clamped address + select, never a guarded load
-  int coff[CT];
-  bool cok[CT];
+  // channel quads past Cb (Cb not a multiple of 128): clamped address + select, never a guarded load
+  const bool cok = c0 + 4 * li < p.Cb;
+  const int coff = min(c0 + 4 * li, p.Cb - 4);
+  f32x16 acc[4];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    cok[ct] = c0 + ct * 32 + li < p.Cb;
-    coff[ct] = min(c0 + ct * 32 + li, p.Cb - 1);
-  }
-  f32x16 acc[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
+  for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
   const int rows = p.N * p.H;
   constexpr int CH = 8;   // k-steps per chunk (16 pixels)
-  float a_cur[CH][CT], b_cur[CH], a_nxt[CH][CT], b_nxt[CH];
+  float4 a_cur[CH], a_nxt[CH];
+  float b_cur[CH], b_nxt[CH];
   for (int row = wave_in_grid; row < rows; row += nwaves) {
     const int y = row % p.H;
     const int ys = y + dyj;
     const bool rowok = jtap && ys >= 0 && ys < p.H;
     const float* srow = p.small + ((int64_t)(row - y + min(max(ys, 0), p.H - 1)) * p.W) * p.Cs + cs;
-    const int64_t brow = (int64_t)row * p.W * p.Cb;
-    auto load_chunk = [&](int x0, float (&a)[CH][CT], float (&b)[CH]) {
+    const float* brow = p.big + (int64_t)row * p.W * p.Cb + coff;
+    auto load_chunk = [&](int x0, float4 (&a)[CH], float (&b)[CH]) {
 #pragma unroll
       for (int s = 0; s < CH; ++s) {
         const int x = x0 + 2 * s + kk;
-        const float* ap = p.big + brow + (int64_t)x * p.Cb;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) { const float v = ap[coff[ct]]; a[s][ct] = cok[ct] ? v : 0.f; }
+        const float4 v4 = *reinterpret_cast<const float4*>(brow + (int64_t)x * p.Cb);
+        a[s] = cok ? v4 : make_float4(0.f, 0.f, 0.f, 0.f);
         const int xs = x + dxj;
         const float v = srow[(int64_t)min(max(xs, 0), p.W - 1) * p.Cs];
         b[s] = ones ? 1.f : ((rowok && xs >= 0 && xs < p.W) ? v : 0.f);
@@ -561,24 +557,23 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_kernel(ThinParams p) {
       if (x0 + 2 * CH < p.W) load_chunk(x0 + 2 * CH, a_nxt, b_nxt);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < CH; ++s)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma32(a_cur[s][ct], b_cur[s], acc[ct]);
+      for (int s = 0; s < CH; ++s) {
+        acc[0] = mfma32(a_cur[s].x, b_cur[s], acc[0]);
+        acc[1] = mfma32(a_cur[s].y, b_cur[s], acc[1]);
+        acc[2] = mfma32(a_cur[s].z, b_cur[s], acc[2]);
+        acc[3] = mfma32(a_cur[s].w, b_cur[s], acc[3]);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < CH; ++s) {
-        b_cur[s] = b_nxt[s];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) a_cur[s][ct] = a_nxt[s][ct];
-      }
+      for (int s = 0; s < CH; ++s) { b_cur[s] = b_nxt[s]; a_cur[s] = a_nxt[s]; }
     }
   }
   float* sl = p.slab + (int64_t)wave_in_grid * p.CbP * 32;
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
+  for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = c0 + ct * 32 + acc_row(r, lane);
+      const int c = c0 + 4 * acc_row(r, lane) + ct;
       if (c < p.Cb) sl[c * 32 + li] = acc[ct][r];
     }
 }
@@ -599,17 +594,39 @@ __global__ __launch_bounds__(256) void thin_colsum_kernel(const float* __restric
 __global__ void conv3x3_wgrad_thin_reduce_kernel(const float* __restrict__ slab, int nwaves, int Cb, int Cs, int CbP, int sign,
                                                  const float* __restrict__ bpart, int nbpart, int Cin, int Cout,
                                                  float* __restrict__ dw, float* __restrict__ dbias) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  // block = 16 outputs x 16 parts: part q sums slabs q, q+16, ... (eight loads in flight), then the 16 parts are added in
+  // a fixed order -- 2048 slabs are far too long a chain for one thread per output
+  __shared__ float red[16][17];
+  const int part = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + (threadIdx.x & 15);
   if (idx < Cb * 32) {
     const int c = idx / 32, j = idx % 32;
+    float ps = 0.f;
+    const float* src = slab + (int64_t)c * 32 + j;
+    const int64_t wstride = (int64_t)CbP * 32;
+    int w = part;
+    for (; w + 7 * 16 < nwaves; w += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(w + 16 * u) * wstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ps += v[u];
+    }
+    for (; w < nwaves; w += 16) ps += src[w * wstride];
+    red[part][threadIdx.x & 15] = ps;
+  }
+  __syncthreads();
+  if (part == 0 && idx < Cb * 32) {
+    const int c = idx / 32, j = idx % 32;
     float s = 0.f;
-    for (int w = 0; w < nwaves; ++w) s += slab[((int64_t)w * CbP + c) * 32 + j];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x & 15];
     if (j < 9 * Cs) {
       const int tap = j / Cs, cs = j % Cs;
       const int co = sign > 0 ? c : cs, ci = sign > 0 ? cs : c;
       dw[((int64_t)co * Cin + ci) * 9 + tap] = s;
     } else if (sign > 0 && dbias && j == 9 * Cs) dbias[c] = s;
-  } else if (sign < 0 && dbias && idx - Cb * 32 < Cout) {
+  } else if (part == 0 && sign < 0 && dbias && idx >= Cb * 32 && idx - Cb * 32 < Cout) {
     const int co = idx - Cb * 32;
     float s = 0.f;
     for (int b = 0; b < nbpart; ++b) s += bpart[b * Cs + co];
@@ -659,11 +676,11 @@ Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
 }
 
 // thin-side kernel: stride-1 conv whose input or output has <= 3 channels (conv_in / conv_out)
-constexpr int THIN_BLOCKS = 512, THIN_BIAS_BLOCKS = 256;
+constexpr int THIN_BLOCKS = 1024, THIN_BIAS_BLOCKS = 256;
 bool thin_applies(int mode, int Hi, int Wi, int Cin, int Cout) {
   static const bool off = getenv("ODVAE_WGRAD_V1") != nullptr;
   const int cb = Cin <= 3 ? Cout : Cin;
-  return !off && mode == 0 && (Cin <= 3) != (Cout <= 3) && Wi % 16 == 0 && cb % 32 == 0 &&
+  return !off && mode == 0 && (Cin <= 3) != (Cout <= 3) && Wi % 16 == 0 && cb % 4 == 0 && cb >= 32 &&
          (int64_t)Hi * Wi * cb * 4 < 0x7FFFFFF0ll;
 }
 size_t thin_workspace_floats(int Cin, int Cout) {
@@ -721,7 +738,7 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
     t.sign = in_thin ? 1 : -1; t.ones_col = (in_thin && dbias) ? 9 * t.Cs : -1;
     const int groups = ceil_div(t.Cb, 128);
     const int blocks = std::max(1, std::min(THIN_BLOCKS / groups, ceil_div(N * Hi, 4)));
-    hipLaunchKernelGGL((conv3x3_wgrad_thin_kernel<4>), dim3(blocks, groups), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(conv3x3_wgrad_thin_kernel, dim3(blocks, groups), dim3(256), 0, st, t);
     ODVAE_LAUNCH_CHECK("conv3x3_wgrad thin");
     float* bpart = t.slab + (size_t)THIN_BLOCKS * 4 * t.Cb * 32;
     if (!in_thin && dbias) {
@@ -729,7 +746,7 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
       ODVAE_LAUNCH_CHECK("conv3x3_wgrad thin bias");
     }
     const int items = t.Cb * 32 + (in_thin ? 0 : Cout);
-    hipLaunchKernelGGL(conv3x3_wgrad_thin_reduce_kernel, dim3(ceil_div(items, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(conv3x3_wgrad_thin_reduce_kernel, dim3(ceil_div(items, 16)), dim3(256), 0, st,
                        t.slab, blocks * 4, t.Cb, t.Cs, t.CbP, t.sign, bpart, THIN_BIAS_BLOCKS, Cin, Cout, dw, dbias);
     ODVAE_LAUNCH_CHECK("conv3x3_wgrad thin reduce");
     return ODVAE_OK;
