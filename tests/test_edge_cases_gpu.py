@@ -1,0 +1,83 @@
+"""Edge cases of the training step the reference's own code paths single out, HIP path vs oracle:
+samples of class id 1 are masked out of every loss term (BACKGROUND_CLASS_IDX = 1, contperceptual.py:17,228), a batch
+with no unmasked sample takes the `else 0` branches (:129,155-163,187,204,210), the 2-d box mask multiplies input and
+reconstruction (autoencoder.py:252-257), the untouched yaml starts in the encoder-pretraining phase (decoder skipped,
+dropout p = 1; autoencoder.py:184-206,246-247), and a batch of one.  Tolerances as in test_model_gpu.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_model_gpu import build_pair, rel  # noqa: E402
+
+
+def _batch(classes, size=64, seed=11, holes=True):
+    from odvae_amd import synthetic
+    batch = synthetic.make_batch(len(classes), size, seed=seed)
+    batch["class_id"] = torch.tensor(classes, dtype=torch.int64)
+    batch["class_name"] = [synthetic.LABELS[c] for c in classes]
+    if holes:   # a real 2-d box mask: zero outside a rectangle that differs per sample
+        m = torch.zeros(len(classes), 1, size, size)
+        for i in range(len(classes)):
+            m[i, :, 4 + 3 * i:size - 6, 2 * i:size - 9 - i] = 1.0
+        batch["mask_2d_bbox"] = m
+    return batch
+
+
+def _compare(model, ref, batch, noise, grad_tol=5e-3):
+    model.train(); ref.train()
+    model.zero_grad(set_to_none=True)
+    model.injected_noise = noise
+    loss = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0, 0)
+    loss_ref, log_ref, _ = ref.training_step(batch, 0, noise)
+    assert torch.isfinite(loss).all()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-3 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    for key, want in log_ref.items():
+        got = model.logged_metrics.get(key)
+        if got is None or not torch.is_tensor(want) or want.numel() != 1:
+            continue
+        if key.endswith(("g_loss", "d_weight")):   # disc_factor = 0: D is not evaluated here, g_loss is logged as 0
+            continue
+        a, b = float(got), float(want)
+        assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (key, a, b)
+    if loss.requires_grad:
+        loss.backward()
+    if loss_ref.requires_grad:
+        loss_ref.backward()
+    ref_params = dict(ref.named_parameters())
+    grads = [p.grad.abs().max().item() for p in ref_params.values() if p.grad is not None]
+    scale = max(grads) if grads else 0.0
+    for name, p in model.named_parameters():
+        rg = ref_params[name].grad
+        g = p.grad
+        if rg is None or scale == 0.0:
+            assert g is None or g.abs().max().item() <= 1e-6 * max(scale, 1.0), name
+            continue
+        assert g is not None, name
+        e = (g.detach().cpu().double() - rg.double()).abs().max().item() / max(rg.abs().max().item(), 1e-3 * scale)
+        assert e < grad_tol, "param grad %s rel err %.3e" % (name, e)
+
+
+def test_masked_class_and_box_mask(hip_lib):
+    from odvae_amd import synthetic
+    model, ref = build_pair()
+    _compare(model, ref, _batch([0, 1, 3, 1]), synthetic.make_noise(4, 4, dropout_p=0.7, seed=21))
+
+
+def test_batch_without_any_unmasked_sample(hip_lib):
+    from odvae_amd import synthetic
+    model, ref = build_pair()
+    _compare(model, ref, _batch([1, 1]), synthetic.make_noise(2, 4, dropout_p=0.7, seed=22))
+
+
+def test_untouched_thresholds_start_in_encoder_pretraining(hip_lib):
+    from odvae_amd import synthetic
+    model, ref = build_pair(phase="asis")
+    assert model._get_dropout_prob() == 1.0
+    _compare(model, ref, _batch([0, 2, 1], holes=False), synthetic.make_noise(3, 4, dropout_p=1.0, seed=23))
+
+
+def test_batch_of_one(hip_lib):
+    from odvae_amd import synthetic
+    model, ref = build_pair()
+    _compare(model, ref, _batch([5]), synthetic.make_noise(1, 4, dropout_p=0.7, seed=24))

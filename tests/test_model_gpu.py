@@ -17,13 +17,13 @@ def rel(a, b):
     return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
 
 
-def build_pair(perceptual_weight=0.0, disc_factor=0.0, latent_hw=4, activation_checkpoint=False):
+def build_pair(perceptual_weight=0.0, disc_factor=0.0, latent_hw=4, activation_checkpoint=False, phase="vae"):
     from odvae_amd import synthetic
     from odvae_amd.config import instantiate_from_config
     from oracle.autoencoder import PoseAutoencoder as OraclePA
     torch.manual_seed(23)
     mcfg, cfg = synthetic.model_config(YAML, latent_hw=latent_hw, ch=32, perceptual_weight=perceptual_weight,
-                                       disc_factor=disc_factor)
+                                       disc_factor=disc_factor, phase=phase)
     if activation_checkpoint:
         mcfg.params.ddconfig["activation_checkpoint"] = True
     model = instantiate_from_config(mcfg)
