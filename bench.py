@@ -69,6 +69,7 @@ def cpu_baseline(res, batch=1, steps=1):
                    dropout_prob_final=p["dropout_prob_final"], dropout_warmup_steps=p["dropout_warmup_steps"],
                    pose_conditioned_generation_steps=p["pose_conditioned_generation_steps"])
     ref.learning_rate = 12 * 4.5e-6
+    ref.global_step = 1   # as on the GPU: past the very first step, whose total holds the pose terms only (contperceptual.py:307)
     opts = ref.configure_optimizers()
     batch_d = synthetic.make_batch(batch, res, seed=23)
     noise = synthetic.make_noise(batch, lat, seed=24)
@@ -108,6 +109,10 @@ def main():
     gan = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if args.gan else {}
     model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gan).to(dev)
     model.train()
+    # steady state: past the very first optimizer step, whose total holds the pose terms only (`global_step >
+    # encoder_pretrain_steps`, contperceptual.py:307) and would skip the decoder's backward pass -- every timed step does the
+    # full forward + backward + optimizer work even with --warmup 0
+    model._global_step = 1
     trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if args.gan else (0,),
                       process_group=dist.group.WORLD if use_dist else None)
     batch = synthetic.make_batch(args.batch, args.res, seed=23 + rank)
