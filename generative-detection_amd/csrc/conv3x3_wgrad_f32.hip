@@ -648,7 +648,7 @@ Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
     pl.ntiles = pl.tiles_x * pl.tiles_y * N;
     pl.CinP = ceil_div(Cin, UP_BC) * UP_BC; pl.CoutP = ceil_div(Cout, UP_BC) * UP_BC;
     pl.ci_tiles = pl.CinP / UP_BC; pl.co_tiles = pl.CoutP / UP_BC;
-    int nsplit = ceil_div(512, pl.ci_tiles * pl.co_tiles);
+    int nsplit = ceil_div(256, pl.ci_tiles * pl.co_tiles);   // one 8-wave block per CU, one round: fewer slabs to write and sum
     if (nsplit > pl.ntiles) nsplit = pl.ntiles;
     if (nsplit < 1) nsplit = 1;
     pl.tiles_per_split = ceil_div(pl.ntiles, nsplit);
@@ -667,7 +667,8 @@ Plan make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
   pl.ci_tiles = pl.CinP / bci;
   pl.co_tiles = pl.CoutP / bco;
   const int ctiles = pl.ci_tiles * pl.co_tiles;
-  int nsplit = ceil_div(pl.v2 ? 512 : 1024, ctiles);   // v2 runs one 8-wave block per CU
+  static const int v2_blocks = getenv("ODVAE_WGRAD_BLOCKS") ? atoi(getenv("ODVAE_WGRAD_BLOCKS")) : 256;   // one block per CU, one round (512: -3..-10 %)
+  int nsplit = ceil_div(pl.v2 ? v2_blocks : 1024, ctiles);   // v2 runs one 8-wave block per CU
   if (nsplit > pl.ntiles) nsplit = pl.ntiles;
   if (nsplit < 1) nsplit = 1;
   pl.tiles_per_split = ceil_div(pl.ntiles, nsplit);

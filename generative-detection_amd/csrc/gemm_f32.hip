@@ -218,8 +218,9 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
 
 int choose_splits(int M, int N, int K, int batch) {
   const int64_t tiles = (int64_t)ceil_div(M, BM) * ceil_div(N, BN) * batch;
+  static const int target = getenv("ODVAE_GEMM_SPLIT_BLOCKS") ? atoi(getenv("ODVAE_GEMM_SPLIT_BLOCKS")) : 1024;
   if (tiles >= 512 || K <= 1024) return 1;
-  int64_t s = 1024 / tiles;
+  int64_t s = target / tiles;
   const int64_t max_by_k = K / 512;  // at least 16 k-tiles per split
   if (s > max_by_k) s = max_by_k;
   if (s < 1) s = 1;
