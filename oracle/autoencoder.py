@@ -138,6 +138,22 @@ class PoseAutoencoder(nn.Module):
                               self.global_step, batch["mask_2d_bbox"], last_layer=self.decoder.conv_out.weight, split="train")
         return loss, log, dict(rgb_gt=rgb_gt, dec_obj=dec_obj, dec_pose=dec_pose, posterior=posterior_obj)
 
+    def validation_step(self, batch, noise):
+        """src/models/autoencoder.py:332-363: one forward, the loss evaluated for optimizer 0 and 1 with split="val";
+        returns the merged log dict (val/rec_loss included)."""
+        rgb_gt = self._rescale(batch["patch"].float())
+        pose_gt = batch["pose_6d"].clone().float()
+        if self.train_on_yaw:
+            pose_gt[:, 3] = batch["yaw"]
+        dec_obj, dec_pose, posterior_obj, bbox_posterior = self.forward(rgb_gt, noise)
+        logs = {}
+        for optimizer_idx in (0, 1):
+            _, log = self.loss(rgb_gt, None, pose_gt, dec_obj, dec_pose, batch["class_id"], batch["class_name"],
+                               batch["bbox_sizes"], batch["fill_factor"].float(), posterior_obj, bbox_posterior, optimizer_idx,
+                               self.global_step, batch["mask_2d_bbox"], last_layer=self.decoder.conv_out.weight, split="val")
+            logs.update(log)
+        return logs
+
     def configure_optimizers(self):
         lr = self.learning_rate
         ae = (list(self.encoder.parameters()) + list(self.decoder.parameters()) + list(self.quant_conv_obj.parameters())

@@ -237,7 +237,11 @@ class PoseLoss(nn.Module):
             logits_fake = self.discriminator(reconstructions.contiguous()) * bg4
             g_loss = -torch.mean(logits_fake)
             if self.disc_factor > 0.0 and global_step > self.encoder_pretrain_steps:
-                d_weight = self.calculate_adaptive_weight(nll_loss, g_loss, last_layer=last_layer)
+                try:
+                    d_weight = self.calculate_adaptive_weight(nll_loss, g_loss, last_layer=last_layer)
+                except RuntimeError:   # no graph under torch.no_grad(): validation (contperceptual.py:295-299)
+                    assert not self.training
+                    d_weight = torch.tensor(0.0)
             else:
                 d_weight = torch.tensor(0.0)
             disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_iter_start)

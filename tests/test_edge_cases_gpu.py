@@ -80,6 +80,32 @@ def test_untouched_thresholds_start_in_encoder_pretraining(hip_lib):
     _compare(model, ref, _batch([0, 2, 1], holes=False), synthetic.make_noise(3, 4, dropout_p=1.0, seed=23), global_step=0)
 
 
+def test_validation_step_logs_match_oracle(hip_lib):
+    """validation_step (autoencoder.py:332-363): eval mode, no graph, GAN + LPIPS-style terms on -- the adaptive weight
+    cannot be differentiated there and falls back to 0 (contperceptual.py:295-299); z-dropout stays active because the
+    reference builds a fresh nn.Dropout inside forward."""
+    from odvae_amd import synthetic
+    model, ref = build_pair(perceptual_weight=1.0, disc_factor=1.0)
+    model.eval(); ref.eval()
+    model._global_step = ref.global_step = 3
+    batch = _batch([0, 1, 4], seed=41)
+    noise = synthetic.make_noise(3, 4, dropout_p=0.7, seed=42)
+    model.injected_noise = noise
+    with torch.no_grad():
+        model.validation_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0)
+        want = ref.validation_step(batch, noise)
+    got = model.logged_metrics
+    checked = 0
+    for key, w in want.items():
+        if not torch.is_tensor(w) or w.numel() != 1:
+            continue
+        assert key in got, key
+        a, b = float(got[key]), float(w)
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (key, a, b)
+        checked += 1
+    assert checked >= 10 and float(got["val/d_weight"]) == 0.0 and "val/disc_loss" in got
+
+
 def test_batch_of_one(hip_lib):
     from odvae_amd import synthetic
     model, ref = build_pair()
