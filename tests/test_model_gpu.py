@@ -157,6 +157,35 @@ def test_three_step_loss_curve_matches_oracle(hip_lib):
             assert diff <= 2.2 * lr * steps + 5e-3 * ref_sd[k].abs().max().item(), (k, diff)
 
 
+def test_config1_golden_curve_at_full_width(hip_lib):
+    """BASELINE.json configs[0] (yaml at full width, 64x64, B=2, 10 steps) on the HIP path against the committed fixture
+    tests/golden/oracle_config1.npz: same initial weights (the generator's seeded oracle), same batches and noise."""
+    import importlib.util
+    import numpy as np
+    from odvae_amd import synthetic
+    from odvae_amd.trainer import Trainer
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(gold_dir, "make_oracle_goldens.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(gold_dir, "oracle_config1.npz"))
+    ref = gen.build_oracle()                                     # seeded initial weights only; it is not trained here
+    model = synthetic.build_model(YAML, batch_size_for_lr=2, latent_hw=4)
+    res = model.load_state_dict(ref.state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to("cuda:0").train()
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,))
+    curve = []
+    for step in range(10):
+        batch = synthetic.make_batch(2, 64, seed=1000 + step)
+        model.injected_noise = synthetic.make_noise(2, 4, dropout_p=0.7, seed=2000 + step)
+        curve.append(trainer.training_batch(batch, step)[0].item())
+        if step == 0:
+            for k in ("kl_loss_obj", "nll_loss", "rec_loss", "pose_loss", "class_loss", "bbox_loss", "kl_loss_bbox"):
+                assert abs(float(model.logged_metrics["train/" + k]) - float(gold["log." + k])) <= 1e-3 * max(1.0, abs(float(gold["log." + k]))), k
+    assert np.allclose(np.array(curve), gold["curve"], rtol=3e-3), (curve, gold["curve"])
+
+
 def _step_with_grads(model, batch, noise):
     model.zero_grad(set_to_none=True)
     model._global_step = 1   # > encoder_pretrain_steps (0): the reconstruction / KL terms are in the total, the decoder gets gradients
