@@ -10,6 +10,7 @@ import logging
 import torch
 import torch.nn as nn
 
+from . import lib as _lib
 from . import ops
 from .config import instantiate_from_config
 from .distributions import DiagonalGaussianDistribution
@@ -210,7 +211,7 @@ class PoseAutoencoder(AutoencoderKL):
                 mask = torch.zeros(z.shape)
             else:
                 mask = (torch.rand(z.shape) >= p).float() / (1.0 - p)
-        return ops.latent_combine(z, mask.to(z.device), None)
+        return ops.latent_combine(z, _lib.upload(mask, z.device), None)
 
     def forward(self, input_im, sample_posterior=True):
         posterior_obj, pose_feat = self.encode(input_im)
@@ -222,7 +223,7 @@ class PoseAutoencoder(AutoencoderKL):
             z_noise = self._noise("z_noise")
             if z_noise is None:
                 z_noise = torch.randn(tuple(z_obj.shape))  # Normal(0,1).sample(...) on the host, as the reference (:239-240)
-            z_obj = ops.latent_combine(z_obj, None, z_noise.to(self.device))
+            z_obj = ops.latent_combine(z_obj, None, _lib.upload(z_noise, self.device))
         dec_pose, bbox_posterior = self._decode_pose(pose_feat, sample_posterior)
         if self.global_step < self.encoder_pretrain_steps:
             n, _, h, w = input_im.shape

@@ -9,6 +9,7 @@ small 2-d pose-head posteriors ([B, 16], [8, 2]) use stock torch ops, as SURVEY.
 """
 import torch
 
+from . import lib as _lib
 from . import ops
 
 
@@ -54,7 +55,7 @@ class DiagonalGaussianDistribution(object):
         shape = (self.parameters.shape[0], self.parameters.shape[1] // 2) + tuple(self.parameters.shape[2:])
         if eps is None:
             eps = torch.randn(shape)
-        eps = eps.to(device=self.parameters.device)
+        eps = _lib.upload(eps, self.parameters.device)
         if self.deterministic:
             return self.mean + 0.0 * eps
         if self._hip:

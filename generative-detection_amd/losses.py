@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import lib as _lib
 from . import ops
 from .distributions import DiagonalGaussianDistribution
 from .gan import LPIPSStyle, NLayerDiscriminator, weights_init
@@ -181,7 +182,8 @@ class PoseLoss(LPIPSWithDiscriminator):
         if self.use_mask_loss:
             mask_loss = self.mask_loss(mask1, mask2)
             return mask_loss, self.mask_weight * mask_loss
-        return torch.tensor(0.0), torch.tensor(0.0)
+        zero = torch.zeros((), device=mask_bg.device)   # the reference's CPU torch.tensor(0.0), made where it is consumed
+        return zero, zero
 
     def _prior_table(self, device):
         """Per-label prior moments stacked once: {label: row}, mean/var/logvar [L, 8] on `device`."""
@@ -201,8 +203,10 @@ class PoseLoss(LPIPSWithDiscriminator):
         fewer tiny launches per step): [B,8,1] against [B,1,8] -> sum over j."""
         mean, logvar = bbox_posterior.mean, bbox_posterior.logvar           # [B, 8]
         rows, p_mean, p_var, p_logvar = self._prior_table(mean.device)
-        idx = torch.tensor([rows[l] if l != "background" else 0 for l in class_gt], device=mean.device)
-        keep = torch.tensor([0.0 if l == "background" else 1.0 for l in class_gt], device=mean.device)
+        # built on the host, sent through the pinned staging ring: a plain torch.tensor(..., device=...) is a pageable
+        # copy that makes the host wait for every queued kernel
+        idx = _lib.upload(torch.tensor([rows[l] if l != "background" else 0 for l in class_gt]), mean.device)
+        keep = _lib.upload(torch.tensor([0.0 if l == "background" else 1.0 for l in class_gt]), mean.device)
         om, ov, ol = p_mean[idx].unsqueeze(1), p_var[idx].unsqueeze(1), p_logvar[idx].unsqueeze(1)   # [B, 1, 8]
         m, lv = mean.unsqueeze(2), logvar.unsqueeze(2)                                               # [B, 8, 1]
         kl = 0.5 * torch.sum(torch.pow(m - om, 2) / (ov + 1e-5) + torch.exp(lv) / (ov + 1e-5) - 1.0 - lv + ol, dim=2)
@@ -281,9 +285,9 @@ class PoseLoss(LPIPSWithDiscriminator):
                     d_weight = self.calculate_adaptive_weight(nll_loss, g_loss, last_layer=last_layer)
                 except RuntimeError:
                     assert not self.training
-                    d_weight = torch.tensor(0.0)
+                    d_weight = torch.zeros((), device=rgb_gt.device)
             else:
-                d_weight = torch.tensor(0.0)
+                d_weight = torch.zeros((), device=rgb_gt.device)
             disc_factor = adopt_weight(self.disc_factor, global_step, threshold=self.discriminator_iter_start)
 
             pose_only = (weighted_pose_loss + weighted_class_loss + weighted_bbox_loss + weighted_fill_factor_loss
