@@ -49,8 +49,8 @@ def _worker(rank, world, port, out_dir):
 
 def test_two_ranks_one_gpu_lockstep(tmp_path):
     # Spawning = fork + exec; on this GPU pool a process that has already initialised the GPU must not exec, so the
-    # test only runs when this pytest process has not touched the device yet (run the file on its own:
-    # `python -m pytest tests/test_parallel_gpu.py -m gpu`); device_count() does not initialise the GPU.
+    # test only runs while this pytest process has not touched the device yet.  The file name sorts first for that
+    # reason (pytest runs files in alphabetical order); device_count() does not initialise the GPU.
     if torch.cuda.device_count() < 1:
         pytest.skip("no HIP device")
     if torch.cuda.is_initialized():
