@@ -653,7 +653,8 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool narrow = Cout <= 32;
   dim3 block(256);
-  // ODVAE_CONV_V1=1 selects the round-1 per-tap-barrier kernel (kept for in-process A/B timing)
+  // ODVAE_CONV_VARIANT=0 selects the first per-tap-barrier kernel (kept for in-process A/B timing and as the
+  // "before" of profiles/r01_conv3x3_pmc.md); 1 (default) = v2
   static const int variant = getenv("ODVAE_CONV_VARIANT") ? atoi(getenv("ODVAE_CONV_VARIANT")) : 1;
   const bool use_v1 = variant == 0 && mode <= 3;
 #define ODVAE_CONV_LAUNCH(KERNEL, MODE, KC)                                                                      \
@@ -668,13 +669,7 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
     }
   } else {
     switch (mode) {
-      case 0:
-        if (variant == 3 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 16, 2, 2, 2, 2, 3>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
-        else if (variant == 4 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 32, 4, 1, 1, 4>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
-        else if (variant == 5 && !narrow) hipLaunchKernelGGL((conv3x3_kernel_v2<0, 16, 4, 1, 1, 4>), dim3((unsigned)sp, p.CoutP / 128), block, 0, st, p);
-        else if (variant == 2) { ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 16); }
-        else { ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 32); }
-        break;
+      case 0: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 0, 32); break;
       case 1: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 1, 8); break;
       case 2: ODVAE_CONV_LAUNCH(conv3x3_kernel_v2, 2, 32); break;
       case 5:
