@@ -568,6 +568,73 @@ __global__ void conv3x3_pack_up_kernel(const float* __restrict__ w, int Cout, in
   }
 }
 
+// ---- thin input: 3 channels in (conv_in on the RGB crop; the data gradient of conv_out, whose dy has 3 channels) -------
+// K = 9 taps x 3 channels = 27 fits ONE 32-deep MFMA operand, so instead of padding Cin to a 32-channel chunk per tap
+// (10x wasted MFMA work) a wave multiplies a 32-pixel row segment's im2col row block [32 px][27 -> 32] with the whole
+// weight matrix [32][128 co], which it keeps in 64 registers for its lifetime.  No LDS, no barriers; A fragments are
+// gathers from the 25 MB input (cache resident), the output is written once.
+__global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(ConvParams p) {
+  const int lane = threadIdx.x & 63, li = lane & 31, kk = lane >> 5;
+  const int wave_in_grid = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int c0 = blockIdx.y * 128;
+  const int QT = p.CinP / 4;
+  // k-step s of this lane is k = 2s + kk -> (tap, ci) = (k / 3, k % 3), taps past 8 multiply zeros
+  float bw[4][16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = 2 * s + kk, tap = k / 3, ci = k - 3 * tap;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int co = c0 + ct * 32 + li;
+      const float w = p.wpk[((int64_t)min(tap, 8) * QT * p.CoutP + min(co, p.CoutP - 1)) * 4 + ci];
+      bw[ct][s] = (tap < 9 && co < p.CoutP) ? w : 0.f;
+    }
+  }
+  float bv[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) bv[ct] = p.bias ? p.bias[min(c0 + ct * 32 + li, p.Cout - 1)] : 0.f;
+  const int segs = p.Wo / 32;                 // host guarantees Wo % 32 == 0
+  const int ntiles = p.N * p.Ho * segs;
+  const bool relu = p.act != 0;
+  for (int tile = wave_in_grid; tile < ntiles; tile += nwaves) {
+    const int seg = tile % segs, row = tile / segs;       // row = n * Ho + y
+    const int y = row % p.Ho, x0 = seg * 32;
+    float a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = 2 * s + kk, tap = k / 3, ci = k - 3 * tap;
+      const int iy = y + tap / 3 - 1, ix = x0 + li + tap % 3 - 1;
+      const bool ok = tap < 9 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      const float v = p.x[((int64_t)(row - y + min(max(iy, 0), p.Hi - 1)) * p.Wi + min(max(ix, 0), p.Wi - 1)) * 3 + ci];
+      a[s] = ok ? v : 0.f;
+    }
+    f32x16 acc[4];
+    const int64_t obase = ((int64_t)row * p.Wo + x0) * p.Cout;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int co = c0 + ct * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[ct][r] = bv[ct] + ((p.residual && co < p.Cout) ? p.residual[obase + (int64_t)acc_row(r, lane) * p.Cout + co] : 0.f);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(a[s], bw[ct][s], acc[ct]);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int co = c0 + ct * 32 + li;
+      if (co < p.Cout) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[ct][r];
+          p.y[obase + (int64_t)acc_row(r, lane) * p.Cout + co] = relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+  }
+}
+
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 }  // namespace
@@ -653,6 +720,14 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool narrow = Cout <= 32;
   dim3 block(256);
+  static const bool thin_off = getenv("ODVAE_CONV_THIN_OFF") != nullptr;
+  if (mode == 0 && Cin == 3 && Wo % 32 == 0 && !thin_off) {
+    const int64_t ntiles = (int64_t)N * Ho * (Wo / 32);
+    const int blocks = (int)std::min<int64_t>(1024, ceil_div64(ntiles, 4));
+    hipLaunchKernelGGL(conv3x3_thin_in_kernel, dim3(blocks, ceil_div(Cout, 128)), block, 0, st, p);
+    ODVAE_LAUNCH_CHECK("conv3x3 thin-in");
+    return ODVAE_OK;
+  }
   // ODVAE_CONV_VARIANT=0 selects the first per-tap-barrier kernel (kept for in-process A/B timing and as the
   // "before" of profiles/r01_conv3x3_pmc.md); 1 (default) = v2
   static const int variant = getenv("ODVAE_CONV_VARIANT") ? atoi(getenv("ODVAE_CONV_VARIANT")) : 1;
