@@ -156,7 +156,7 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
     else:
         ho, wo = 2 * hi, 2 * wi
     y = _new_cl(n, cout, ho, wo, x)
-    tag = KERNEL_EVENTS.begin() if (mode == 0 and cout > 32) else None
+    tag = KERNEL_EVENTS.begin() if (mode == 0 and cout > 32 and cin > 3) else None   # the 128-wide v2 kernel only
     _lib.check(L.odvae_conv3x3_f32(mode, x.data_ptr(), n, hi, wi, cin, pack.data_ptr(), cout,
                                    _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, int(act), _lib.stream_ptr()),
                "conv3x3(mode=%d)" % mode)
