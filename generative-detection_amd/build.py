@@ -13,6 +13,7 @@ HIP_SOURCES = ["gemm_f32.hip", "conv3x3_f32.hip", "conv3x3_wgrad_f32.hip", "grou
 CXX_SOURCES = ["runtime.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", CSRC]
+FLAGS += os.environ.get("ODVAE_EXTRA_HIPCC_FLAGS", "").split()   # diagnostic builds (-DODVAE_STAMPS, ...); use with force=True
 
 
 def _stale(target, deps):
