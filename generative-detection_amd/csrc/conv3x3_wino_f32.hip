@@ -1,0 +1,276 @@
+// Stride-1 3x3 convolution by Winograd F(2x2, 3x3), NHWC f32, fused transforms, gfx950.
+//
+// Same contract as mode 0 of conv3x3_f32.hip (ResnetBlock / conv_in / conv_out convs of [UPSTREAM]
+// ldm/modules/diffusionmodules/model.py and their data gradients), 2.25x fewer multiply-adds:
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, d = its 4x4 input patch
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. sixteen independent [tiles x Cin] x [Cin x Cout] products M[xi] = V[xi] U[xi] (xi = position in the 4x4 tile)
+// on the f32 MFMA, with U = G g G^T packed once per weight update (odvae_conv3x3_pack_wino_f32).
+//
+// Block = 4 waves, 8x16 output pixels = 32 tiles (4 x 8) x 64 output channels.  Per 16-channel chunk: the input halo
+// (10 x 18 px) goes global -> registers -> LDS, every thread transforms its share into V [16 xi][32 tiles][16 ch] in
+// LDS, then wave w multiplies row w of the 4x4 (xi = 4w .. 4w+3: A fragments from V, B fragments straight from the
+// L2-resident U pack) into 4 xi x 2 co-tiles of accumulators.  The output transform needs all four rows of a tile:
+// each wave folds its row (M A, registers only), the rows meet through LDS (A^T), and bias / residual / store follow.
+// The arithmetic is f32 throughout; only the summation order differs from the direct form (error ~1e-6 relative).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;           // output pixels per block
+constexpr int NT = (TH / 2) * (TW / 2);  // 32 tiles of 2x2
+constexpr int TXN = TW / 2;              // tiles per row of the block
+constexpr int HH = TH + 2, HW = TW + 2;  // input halo
+constexpr int KC = 16;                   // channels per chunk
+constexpr int HS = KC + 4;               // halo / V row stride in floats (b128 reads land on distinct bank groups)
+constexpr int BN = 64;                   // output channels per block
+constexpr int HALO_F = HH * HW * HS;     // 3600 floats
+constexpr int V_F = 16 * NT * HS;        // 10240 floats
+
+struct WinoParams {
+  const float* x;         // [N][H][W][Cin]
+  const float* upk;       // [16][CinP/4][CoutP][4]
+  const float* bias;      // [Cout] or null
+  const float* residual;  // [N][H][W][Cout] or null
+  float* y;               // [N][H][W][Cout]
+  int N, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, act;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[HALO_F + V_F];   // 55 360 B: two blocks per CU
+  float* Hs = smem;
+  float* Vs = smem + HALO_F;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN;
+  const float* xn = p.x + (int64_t)n * p.H * p.W * p.Cin;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, p.H * p.W * p.Cin * 4, 0x00020000);
+
+  // ---- halo: 180 px x 4 channel quads = 720 float4 per chunk, 3 per thread (branch-free buffer loads) ----
+  constexpr int HALO_F4 = HH * HW * (KC / 4);
+  constexpr int HALO_IT = (HALO_F4 + 255) / 256;
+  float4 hreg[HALO_IT];
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      const int hp = f >> 2, q = f & 3;
+      const int iy = oy0 - 1 + hp / HW, ix = ox0 - 1 + hp % HW;
+      const int c = c0 + 4 * q;
+      const bool ok = f < HALO_F4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
+      const unsigned voff = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + c) * 4) : 0x7FFFFFF0u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+      hreg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      if (f < HALO_F4) *reinterpret_cast<float4*>(Hs + (f >> 2) * HS + 4 * (f & 3)) = hreg[i];
+    }
+  };
+  // ---- input transform: thread = (tile, channel quad, row pair); V rows {0,1} need d rows 0..2, rows {2,3} rows 1..3 ----
+  auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+  auto transform = [&]() {
+    const int tile = tid >> 3, q = (tid >> 1) & 3, rp = tid & 1;     // 32 tiles x 4 quads x 2 row pairs
+    const int ty2 = 2 * (tile / TXN), tx2 = 2 * (tile % TXN);
+    float4 d[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        d[r][c] = *reinterpret_cast<const float4*>(Hs + ((ty2 + rp + r) * HW + tx2 + c) * HS + 4 * q);
+    // rows of B^T d:  rp 0: r0 = d0 - d2, r1 = d1 + d2 ;  rp 1 (d holds rows 1,2,3): r2 = d2 - d1, r3 = d1 - d3
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (rp == 0) { ra[c] = f4sub(d[0][c], d[2][c]); rb[c] = f4add(d[1][c], d[2][c]); }
+      else { ra[c] = f4sub(d[1][c], d[0][c]); rb[c] = f4sub(d[0][c], d[2][c]); }
+    }
+    // times B: columns  c0 = r0 - r2, c1 = r1 + r2, c2 = r2 - r1, c3 = r1 - r3
+    const float4 va[4] = {f4sub(ra[0], ra[2]), f4add(ra[1], ra[2]), f4sub(ra[2], ra[1]), f4sub(ra[1], ra[3])};
+    const float4 vb[4] = {f4sub(rb[0], rb[2]), f4add(rb[1], rb[2]), f4sub(rb[2], rb[1]), f4sub(rb[1], rb[3])};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<float4*>(Vs + (((2 * rp + 0) * 4 + c) * NT + tile) * HS + 4 * q) = va[c];
+      *reinterpret_cast<float4*>(Vs + (((2 * rp + 1) * 4 + c) * NT + tile) * HS + 4 * q) = vb[c];
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+
+  const float4* uq = reinterpret_cast<const float4*>(p.upk);
+  const int QT = p.CinP / 4;
+  const int nchunks = p.CinP / KC;
+  load_halo(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();            // the previous chunk's V reads are done
+    store_halo();
+    __syncthreads();
+    if (ch + 1 < nchunks) load_halo((ch + 1) * KC);
+    transform();
+    __syncthreads();
+    // wave `wave` = row of the 4x4: xi = 4 wave + j.  k order inside a group of 8 channels: step s of lane half h is
+    // channel 8g + 4h + s on both operands
+#pragma unroll
+    for (int g = 0; g < KC / 8; ++g) {
+      float4 a[4], b[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = *reinterpret_cast<const float4*>(Vs + (((wave * 4 + j) * NT) + li) * HS + 8 * g + 4 * h);
+        const int64_t base = ((int64_t)(wave * 4 + j) * QT + ch * (KC / 4) + 2 * g + h) * p.CoutP + n0 + li;
+        b[j][0] = uq[base];
+        b[j][1] = uq[base + 32];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[j][nt] = mfma32(a[j].x, b[j][nt].x, acc[j][nt]);
+          acc[j][nt] = mfma32(a[j].y, b[j][nt].y, acc[j][nt]);
+          acc[j][nt] = mfma32(a[j].z, b[j][nt].z, acc[j][nt]);
+          acc[j][nt] = mfma32(a[j].w, b[j][nt].w, acc[j][nt]);
+        }
+    }
+  }
+
+  // ---- output transform.  Row fold in registers: R0 = m0 + m1 + m2, R1 = m1 - m2 - m3 (over j); then the four rows
+  // (waves) meet in LDS: Y[0][c] = R(0) + R(1) + R(2), Y[1][c] = R(1) - R(2) - R(3) ----
+  __syncthreads();              // V is dead: reuse smem as X[wave][c][nt][reg][lane] = 4*2*2*16*64 floats = 64 KB > smem,
+                                // so one co-tile at a time: X[wave][c][reg][lane] = 32 KB
+  float* X = smem;
+  const int img_bytes = p.H * p.W * p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+  const bool relu = p.act != 0;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+      X[((wave * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
+      X[((wave * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+    }
+    __syncthreads();
+    // wave w finishes registers r = 4w .. 4w+3 (tiles (r&3) + 8(r>>2) + 4h): 4 output pixels each
+    const int co = n0 + nt * 32 + li;
+    const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int py = oy0 + 2 * (tile / TXN), px = ox0 + 2 * (tile % TXN);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float r0 = X[((0 * 2 + c) * 16 + r) * 64 + lane], r1 = X[((1 * 2 + c) * 16 + r) * 64 + lane];
+        const float r2 = X[((2 * 2 + c) * 16 + r) * 64 + lane], r3 = X[((3 * 2 + c) * 16 + r) * 64 + lane];
+        const float y0 = r0 + r1 + r2 + bv, y1 = r1 - r2 - r3 + bv;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int oy = py + a, ox = px + c;
+          const unsigned off = (oy < p.H && ox < p.W && co < p.Cout) ? (unsigned)(((oy * p.W + ox) * p.Cout + co) * 4) : 0x7FFFFFF0u;
+          float v = a == 0 ? y0 : y1;
+          if (p.residual) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, off, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(v, 0.f) : v), yrsrc, off, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // X is rewritten for the next co-tile
+  }
+}
+
+// U[xi = 4a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles
+__global__ void conv3x3_pack_wino_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                         float* __restrict__ fwd, int CinP_f, int CoutP_f,
+                                         float* __restrict__ dgr, int CoutP_d, int CinP_d) {
+  const int64_t nf = fwd ? (int64_t)16 * CinP_f * CoutP_f : 0;
+  const int64_t nd = dgr ? (int64_t)16 * CoutP_d * CinP_d : 0;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool is_f = idx < nf;
+    int64_t r = is_f ? idx : idx - nf;
+    const int outP = is_f ? CoutP_f : CinP_d, redP = is_f ? CinP_f : CoutP_d;
+    const int j = r & 3; r >>= 2;
+    const int o = (int)(r % outP); r /= outP;
+    const int q = (int)(r % (redP / 4)); const int xi = (int)(r / (redP / 4));
+    const int red = 4 * q + j;
+    const int co = is_f ? o : red, ci = is_f ? red : o;
+    float u = 0.f;
+    if (co < Cout && ci < Cin) {
+      const float* g = w + ((int64_t)co * Cin + ci) * 9;
+      const int a = xi >> 2, b = xi & 3;
+      for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+          const float gv = is_f ? g[kh * 3 + kw] : g[(2 - kh) * 3 + (2 - kw)];
+          u += G[a][kh] * gv * G[b][kw];
+        }
+    }
+    (is_f ? fwd : dgr)[is_f ? idx : idx - nf] = u;
+  }
+}
+
+constexpr int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" {
+
+// pack sizes: reduction axis padded to 16, output axis to 64
+int odvae_conv3x3_wino_reduce_pad(int c_reduce) { return round_up_i(c_reduce, KC); }
+int odvae_conv3x3_wino_out_pad(int c_out) { return round_up_i(c_out, BN); }
+size_t odvae_conv3x3_wino_pack_floats(int c_reduce, int c_out) {
+  return (size_t)16 * odvae_conv3x3_wino_reduce_pad(c_reduce) * odvae_conv3x3_wino_out_pad(c_out);
+}
+
+int odvae_conv3x3_pack_wino_f32(const float* w, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream) {
+  ODVAE_CHECK_ARG(w && Cout > 0 && Cin > 0, "conv3x3_pack_wino: bad arguments");
+  const int CinP_f = odvae_conv3x3_wino_reduce_pad(Cin), CoutP_f = odvae_conv3x3_wino_out_pad(Cout);
+  const int CoutP_d = odvae_conv3x3_wino_reduce_pad(Cout), CinP_d = odvae_conv3x3_wino_out_pad(Cin);
+  const int64_t total = (fwd_pack ? (int64_t)16 * CinP_f * CoutP_f : 0) + (dgrad_pack ? (int64_t)16 * CoutP_d * CinP_d : 0);
+  if (total == 0) return ODVAE_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 2048);
+  hipLaunchKernelGGL(conv3x3_pack_wino_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d);
+  ODVAE_LAUNCH_CHECK("conv3x3_pack_wino");
+  return ODVAE_OK;
+}
+
+// y = act(conv3x3_stride1_pad1(x) (+bias) (+residual)); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino_f32.
+// Needs even H and W and Cin % 4 == 0.
+int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                           const float* bias, const float* residual, float* y, int act, void* stream) {
+  ODVAE_CHECK_ARG(x && upk && y, "conv3x3_wino: null operand");
+  ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino: empty shape");
+  ODVAE_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cin % 4 == 0, "conv3x3_wino: needs even H, W and Cin %% 4 == 0 (H=%d W=%d Cin=%d)", H, W, Cin);
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)upk & 15) == 0, "conv3x3_wino: x/upk must be 16-byte aligned");
+  ODVAE_CHECK_ARG((int64_t)H * W * Cin * 4 < 0x7FFFFFF0ll && (int64_t)H * W * Cout * 4 < 0x7FFFFFF0ll,
+                  "conv3x3_wino: one input / output image must stay below 2 GiB");
+  WinoParams p;
+  p.x = x; p.upk = upk; p.bias = bias; p.residual = residual; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.CinP = odvae_conv3x3_wino_reduce_pad(Cin); p.CoutP = odvae_conv3x3_wino_out_pad(Cout);
+  p.tiles_x = ceil_div(W, TW); p.tiles_y = ceil_div(H, TH); p.act = act;
+  const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
+  ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino: too many tiles");
+  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  ODVAE_LAUNCH_CHECK("conv3x3_wino");
+  return ODVAE_OK;
+}
+
+}  // extern "C"

@@ -26,6 +26,11 @@ PROTOTYPES = {
     "odvae_conv3x3_pack_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "odvae_conv3x3_up_pack_floats": (_Z, [_I, _I]),
     "odvae_conv3x3_pack_up_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "odvae_conv3x3_wino_reduce_pad": (_I, [_I]),
+    "odvae_conv3x3_wino_out_pad": (_I, [_I]),
+    "odvae_conv3x3_wino_pack_floats": (_Z, [_I, _I]),
+    "odvae_conv3x3_pack_wino_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "odvae_conv3x3_wino_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),

@@ -119,18 +119,21 @@ PACK_CACHE = _PackCache()
 
 
 def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False, up=False):
-    """up=True: the 16-tap packs of an Upsample conv (taps that hit the same low-res pixel pre-summed, modes 5 / 6)."""
+    """up=True: the 16-tap packs of an Upsample conv (taps that hit the same low-res pixel pre-summed, modes 5 / 6);
+    up="wino": the Winograd F(2x2,3x3) packs U = G g G^T of a stride-1 conv (conv3x3_wino_f32.hip)."""
     L = _L()
     w = weight.detach().contiguous()
     _lib.require_device(w)
     cout, cin = w.shape[0], w.shape[1]
-    floats = L.odvae_conv3x3_up_pack_floats if up else L.odvae_conv3x3_pack_floats
+    floats = (L.odvae_conv3x3_wino_pack_floats if up == "wino" else
+              L.odvae_conv3x3_up_pack_floats if up else L.odvae_conv3x3_pack_floats)
     fwd = dgr = None
     if want_fwd:
         fwd = torch.empty(floats(cin, cout), dtype=torch.float32, device=w.device)
     if want_dgrad:
         dgr = torch.empty(floats(cout, cin), dtype=torch.float32, device=w.device)
-    pack = L.odvae_conv3x3_pack_up_f32 if up else L.odvae_conv3x3_pack_f32
+    pack = (L.odvae_conv3x3_pack_wino_f32 if up == "wino" else
+            L.odvae_conv3x3_pack_up_f32 if up else L.odvae_conv3x3_pack_f32)
     _lib.check(pack(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv3x3_pack")
     return fwd, dgr
 
@@ -165,6 +168,28 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
     return y
 
 
+# Stride-1 3x3 convs by Winograd F(2x2, 3x3) (conv3x3_wino_f32.hip) when the shape allows; ODVAE_CONV_WINOGRAD=0 keeps
+# the direct implicit-GEMM kernel everywhere
+WINOGRAD = os.environ.get("ODVAE_CONV_WINOGRAD", "1") != "0"
+
+
+def _wino_ok(h, w, cin, cout):
+    # both the forward (reduce over cin) and the data gradient (reduce over cout) need channel counts in whole quads
+    return WINOGRAD and h % 2 == 0 and w % 2 == 0 and cin % 4 == 0 and cout % 4 == 0 and cin >= 16 and cout >= 16
+
+
+def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0):
+    L = _L()
+    n, _, h, w = x.shape
+    y = _new_cl(n, cout, h, w, x)
+    tag = KERNEL_EVENTS.begin() if cout > 32 else None
+    _lib.check(L.odvae_conv3x3_wino_f32(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                                        y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino")
+    KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
+                      4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout))
+    return y
+
+
 class _Conv3x3(Function):
     """mode 0: stride 1 pad 1; mode 1: Downsample (pad (0,1,0,1), stride 2); mode 2: Upsample (nearest 2x) + conv."""
 
@@ -174,9 +199,14 @@ class _Conv3x3(Function):
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
         up = mode == 2 and UPCONV_BY_PARITY
+        if mode == 0 and _wino_ok(x.shape[2], x.shape[3], cin, cout):
+            up = "wino"
         fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), up)  # both packs in one launch
         b = bias.detach().contiguous() if bias is not None else None
-        y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
+        if up == "wino":
+            y = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
+        else:
+            y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
         ctx.mode, ctx.up = mode, up
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
@@ -201,7 +231,9 @@ class _Conv3x3(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             _, dgr = pack_conv3x3(weight, False, True, ctx.up)
-            if mode == 0:
+            if ctx.up == "wino":
+                dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None)
+            elif mode == 0:
                 dx = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)
             elif mode == 1:
                 dx = _conv3x3_raw(3, dy, dgr, cout, cin, None, None)
@@ -215,7 +247,7 @@ class _Conv3x3(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            wmode = 5 if ctx.up else mode
+            wmode = 5 if ctx.up is True else mode
             need = L.odvae_conv3x3_wgrad_workspace_bytes(wmode, n, ho, wo, cin, cout)
             wp, wn = _ws(need, x)
             _lib.check(L.odvae_conv3x3_wgrad_f32(wmode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,

@@ -72,6 +72,18 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
                       const float* wpk, int Cout, const float* bias, const float* residual,
                       float* y, int Ho, int Wo, int act /* 0 none, 1 ReLU */, void* stream);
 
+/* ---- conv3x3_wino_f32.hip: the stride-1 pad-1 3x3 convolution (mode 0 above and its data gradient) by Winograd
+ * F(2x2, 3x3) with fused input / output transforms: f32 throughout, 2.25x fewer multiply-adds, summation order differs
+ * from the direct form (~1e-6 relative).  Packs: U = G g G^T per (ci, co), [16][reduce_pad/4][out_pad][4] floats;
+ * fwd_pack (reduce = Cin) and/or dgrad_pack (reduce = Cout, taps flipped), either may be NULL.  Needs even H, W and
+ * Cin % 4 == 0. */
+int odvae_conv3x3_wino_reduce_pad(int c_reduce);
+int odvae_conv3x3_wino_out_pad(int c_out);
+size_t odvae_conv3x3_wino_pack_floats(int c_reduce, int c_out);
+int odvae_conv3x3_pack_wino_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
+int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                           const float* bias, const float* residual, float* y, int act /* 0 none, 1 ReLU */, void* stream);
+
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
  * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)
  * dw is OIHW [Cout][Cin][3][3], overwritten; dbias [Cout] or NULL. */
