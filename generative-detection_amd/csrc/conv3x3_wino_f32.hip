@@ -37,9 +37,9 @@ struct WinoParams {
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[HALO_F + V_F];   // 55 360 B: two blocks per CU
-  float* Hs = smem;
-  float* Vs = smem + HALO_F;
+  __shared__ __attribute__((aligned(16))) float smem[2 * HALO_F + V_F];   // 69 760 B: two blocks per CU
+  float* Hs = smem;                  // two halo stages
+  float* Vs = smem + 2 * HALO_F;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,31 +69,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
       hreg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](float* Hd) {
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
       const int f = tid + 256 * i;
-      if (f < HALO_F4) *reinterpret_cast<float4*>(Hs + (f >> 2) * HS + 4 * (f & 3)) = hreg[i];
+      if (f < HALO_F4) *reinterpret_cast<float4*>(Hd + (f >> 2) * HS + 4 * (f & 3)) = hreg[i];
     }
   };
   // ---- input transform: thread = (tile, channel quad, row pair); V rows {0,1} need d rows 0..2, rows {2,3} rows 1..3 ----
   auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
   auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-  auto transform = [&]() {
+  auto transform = [&](const float* Hc) {
     const int tile = tid >> 3, q = (tid >> 1) & 3, rp = tid & 1;     // 32 tiles x 4 quads x 2 row pairs
     const int ty2 = 2 * (tile / TXN), tx2 = 2 * (tile % TXN);
-    float4 d[3][4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        d[r][c] = *reinterpret_cast<const float4*>(Hs + ((ty2 + rp + r) * HW + tx2 + c) * HS + 4 * q);
-    // rows of B^T d:  rp 0: r0 = d0 - d2, r1 = d1 + d2 ;  rp 1 (d holds rows 1,2,3): r2 = d2 - d1, r3 = d1 - d3
+    // rows of B^T d, one column of the patch at a time (keeps 3 float4 live instead of 12):
+    //   rp 0: r0 = d0 - d2, r1 = d1 + d2 ;  rp 1 (rows 1,2,3 loaded): r2 = d2 - d1, r3 = d1 - d3
     float4 ra[4], rb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (rp == 0) { ra[c] = f4sub(d[0][c], d[2][c]); rb[c] = f4add(d[1][c], d[2][c]); }
-      else { ra[c] = f4sub(d[1][c], d[0][c]); rb[c] = f4sub(d[0][c], d[2][c]); }
+      const float* src = Hc + ((ty2 + rp) * HW + tx2 + c) * HS + 4 * q;
+      const float4 d0 = *reinterpret_cast<const float4*>(src);
+      const float4 d1 = *reinterpret_cast<const float4*>(src + HW * HS);
+      const float4 d2 = *reinterpret_cast<const float4*>(src + 2 * HW * HS);
+      if (rp == 0) { ra[c] = f4sub(d0, d2); rb[c] = f4add(d1, d2); }
+      else { ra[c] = f4sub(d1, d0); rb[c] = f4sub(d0, d2); }
     }
     // times B: columns  c0 = r0 - r2, c1 = r1 + r2, c2 = r2 - r1, c3 = r1 - r3
     const float4 va[4] = {f4sub(ra[0], ra[2]), f4add(ra[1], ra[2]), f4sub(ra[2], ra[1]), f4sub(ra[1], ra[3])};
@@ -116,42 +115,66 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
   const float4* uq = reinterpret_cast<const float4*>(p.upk);
   const int QT = p.CinP / 4;
   const int nchunks = p.CinP / KC;
-  load_halo(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    __syncthreads();            // the previous chunk's V reads are done
-    store_halo();
-    __syncthreads();
-    if (ch + 1 < nchunks) load_halo((ch + 1) * KC);
-    transform();
-    __syncthreads();
-    // wave `wave` = row of the 4x4: xi = 4 wave + j.  k order inside a group of 8 channels: step s of lane half h is
-    // channel 8g + 4h + s on both operands
+  // B fragments of step (chunk, group): xi = 4 wave + j, two co tiles
+  auto load_b = [&](int ch, int g, float4 (&b)[4][2]) {
 #pragma unroll
-    for (int g = 0; g < KC / 8; ++g) {
-      float4 a[4], b[4][2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] = *reinterpret_cast<const float4*>(Vs + (((wave * 4 + j) * NT) + li) * HS + 8 * g + 4 * h);
-        const int64_t base = ((int64_t)(wave * 4 + j) * QT + ch * (KC / 4) + 2 * g + h) * p.CoutP + n0 + li;
-        b[j][0] = uq[base];
-        b[j][1] = uq[base + 32];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          acc[j][nt] = mfma32(a[j].x, b[j][nt].x, acc[j][nt]);
-          acc[j][nt] = mfma32(a[j].y, b[j][nt].y, acc[j][nt]);
-          acc[j][nt] = mfma32(a[j].z, b[j][nt].z, acc[j][nt]);
-          acc[j][nt] = mfma32(a[j].w, b[j][nt].w, acc[j][nt]);
-        }
+    for (int j = 0; j < 4; ++j) {
+      const int64_t base = ((int64_t)(wave * 4 + j) * QT + ch * (KC / 4) + 2 * g + h) * p.CoutP + n0 + li;
+      b[j][0] = uq[base];
+      b[j][1] = uq[base + 32];
     }
+  };
+  auto load_a = [&](int g, float4 (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(Vs + (((wave * 4 + j) * NT) + li) * HS + 8 * g + 4 * h);
+  };
+  auto mma = [&](const float4 (&a)[4], const float4 (&b)[4][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[j][nt] = mfma32(a[j].x, b[j][nt].x, acc[j][nt]);
+        acc[j][nt] = mfma32(a[j].y, b[j][nt].y, acc[j][nt]);
+        acc[j][nt] = mfma32(a[j].z, b[j][nt].z, acc[j][nt]);
+        acc[j][nt] = mfma32(a[j].w, b[j][nt].w, acc[j][nt]);
+      }
+  };
+
+  // Two barriers per chunk: the halo is double-buffered in LDS (chunk c+1 is stored while chunk c is multiplied), V is
+  // single-buffered (transform -> barrier -> MFMAs -> barrier).  The two blocks of a CU run these phases out of step, so
+  // one block's transform (VALU + LDS) hides under the other's MFMAs.  Weight fragments are prefetched one group ahead
+  // (across the chunk boundary too), A fragments of group 1 behind the MFMAs of group 0.
+  static_assert(KC == 16, "two k-groups per chunk");
+  float4 b0[4][2], b1[4][2], a[4];
+  load_halo(0);
+  load_b(0, 0, b0);
+  store_halo(Hs);
+  if (nchunks > 1) load_halo(KC);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    transform(Hs + (ch & 1) * HALO_F);
+    __syncthreads();
+    if (ch + 1 < nchunks) {
+      store_halo(Hs + ((ch + 1) & 1) * HALO_F);
+      if (ch + 2 < nchunks) load_halo((ch + 2) * KC);
+    }
+    load_a(0, a);
+    load_b(ch, 1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(1, a);
+    if (ch + 1 < nchunks) load_b(ch + 1, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
   }
 
   // ---- output transform.  Row fold in registers: R0 = m0 + m1 + m2, R1 = m1 - m2 - m3 (over j); then the four rows
   // (waves) meet in LDS: Y[0][c] = R(0) + R(1) + R(2), Y[1][c] = R(1) - R(2) - R(3) ----
-  __syncthreads();              // V is dead: reuse smem as X[wave][c][nt][reg][lane] = 4*2*2*16*64 floats = 64 KB > smem,
-                                // so one co-tile at a time: X[wave][c][reg][lane] = 32 KB
+  // V and the halo stages are dead (the loop ends on a barrier): reuse smem as X[wave][c][reg][lane] = 32 KB, one co
+  // tile at a time
   float* X = smem;
   const int img_bytes = p.H * p.W * p.Cout * 4;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
