@@ -14,6 +14,7 @@
 // each wave folds its row (M A, registers only), the rows meet through LDS (A^T), and bias / residual / store follow.
 // The arithmetic is f32 throughout; only the summation order differs from the direct form (error ~1e-6 relative).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -217,6 +218,191 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
   }
 }
 
+// ---- 8-wave variant: 32 tiles x 128 output channels per block, one block per CU ----------------------------------
+// With 64 output channels a block holds only 512 MFMAs per wave at Cin = 128, so its prologue (first halo fetch + first
+// transform), the transform phases and the output exchange weigh 40 % (measured: 56 % MFMA utilisation).  Here eight
+// waves (4 rows of the 4x4 x 2 co halves) share one V, V is double-buffered as well, and the transform of chunk c+1 sits
+// between the two MFMA groups of chunk c: one barrier per chunk, the transform work per thread halves, and the input
+// transform is done once per 128 output channels instead of once per 64.  111 KB of LDS: one block per CU.
+constexpr int BN8 = 128;
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dsmem[];   // 2 halo stages + 2 V stages
+  float* Hs = dsmem;
+  float* Vs = dsmem + 2 * HALO_F;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xr = wave & 3, half = wave >> 2;          // row of the 4x4, co half
+  const int li = lane & 31, h = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN8 + half * 64;
+  const float* xn = p.x + (int64_t)n * p.H * p.W * p.Cin;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, p.H * p.W * p.Cin * 4, 0x00020000);
+
+  constexpr int HALO_F4 = HH * HW * (KC / 4);           // 720
+  constexpr int HALO_IT = (HALO_F4 + 511) / 512;        // 2
+  float4 hreg[HALO_IT];
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 512 * i;
+      const int hp = f >> 2, q = f & 3;
+      const int iy = oy0 - 1 + hp / HW, ix = ox0 - 1 + hp % HW;
+      const int c = c0 + 4 * q;
+      const bool ok = f < HALO_F4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
+      const unsigned voff = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + c) * 4) : 0x7FFFFFF0u;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+      hreg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto store_halo = [&](float* Hd) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 512 * i;
+      if (f < HALO_F4) *reinterpret_cast<float4*>(Hd + (f >> 2) * HS + 4 * (f & 3)) = hreg[i];
+    }
+  };
+  auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
+  // thread = (tile, channel quad, row pair rp, column pair cp): rows {2rp, 2rp+1} x columns {2cp, 2cp+1} of V
+  auto transform = [&](const float* Hc, float* Vd) {
+    const int tile = tid >> 4, q = (tid >> 2) & 3, rp = (tid >> 1) & 1, cp = tid & 1;
+    const int ty2 = 2 * (tile / TXN), tx2 = 2 * (tile % TXN);
+    float4 ra[3], rb[3];   // rows of B^T d at patch columns cp, cp+1, cp+2
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float* src = Hc + ((ty2 + rp) * HW + tx2 + cp + k) * HS + 4 * q;
+      const float4 d0 = *reinterpret_cast<const float4*>(src);
+      const float4 d1 = *reinterpret_cast<const float4*>(src + HW * HS);
+      const float4 d2 = *reinterpret_cast<const float4*>(src + 2 * HW * HS);
+      if (rp == 0) { ra[k] = f4sub(d0, d2); rb[k] = f4add(d1, d2); }      // r0 = d0 - d2, r1 = d1 + d2
+      else { ra[k] = f4sub(d1, d0); rb[k] = f4sub(d0, d2); }             // r2 = d2 - d1, r3 = d1 - d3 (rows 1,2,3 loaded)
+    }
+    // cp 0: c0 = col0 - col2, c1 = col1 + col2;  cp 1 (cols 1,2,3 loaded): c2 = col2 - col1, c3 = col1 - col3
+    float4 va0, va1, vb0, vb1;
+    if (cp == 0) { va0 = f4sub(ra[0], ra[2]); va1 = f4add(ra[1], ra[2]); vb0 = f4sub(rb[0], rb[2]); vb1 = f4add(rb[1], rb[2]); }
+    else { va0 = f4sub(ra[1], ra[0]); va1 = f4sub(ra[0], ra[2]); vb0 = f4sub(rb[1], rb[0]); vb1 = f4sub(rb[0], rb[2]); }
+    float* dst = Vd + tile * HS + 4 * q;
+    *reinterpret_cast<float4*>(dst + ((2 * rp + 0) * 4 + 2 * cp + 0) * NT * HS) = va0;
+    *reinterpret_cast<float4*>(dst + ((2 * rp + 0) * 4 + 2 * cp + 1) * NT * HS) = va1;
+    *reinterpret_cast<float4*>(dst + ((2 * rp + 1) * 4 + 2 * cp + 0) * NT * HS) = vb0;
+    *reinterpret_cast<float4*>(dst + ((2 * rp + 1) * 4 + 2 * cp + 1) * NT * HS) = vb1;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+
+  const float4* uq = reinterpret_cast<const float4*>(p.upk);
+  const int QT = p.CinP / 4;
+  const int nchunks = p.CinP / KC;
+  auto load_b = [&](int ch, int g, float4 (&b)[4][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t base = ((int64_t)(xr * 4 + j) * QT + ch * (KC / 4) + 2 * g + h) * p.CoutP + n0 + li;
+      b[j][0] = uq[base];
+      b[j][1] = uq[base + 32];
+    }
+  };
+  auto load_a = [&](const float* Vc, int g, float4 (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(Vc + (((xr * 4 + j) * NT) + li) * HS + 8 * g + 4 * h);
+  };
+  auto mma = [&](const float4 (&a)[4], const float4 (&b)[4][2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[j][nt] = mfma32(a[j].x, b[j][nt].x, acc[j][nt]);
+        acc[j][nt] = mfma32(a[j].y, b[j][nt].y, acc[j][nt]);
+        acc[j][nt] = mfma32(a[j].z, b[j][nt].z, acc[j][nt]);
+        acc[j][nt] = mfma32(a[j].w, b[j][nt].w, acc[j][nt]);
+      }
+  };
+
+  // vmcnt retires in order: whatever is waited on makes every OLDER load wait too.  The halo fetch (HBM latency) is
+  // therefore always the YOUNGEST load in flight when something else is awaited: per iteration the order of issue is
+  // b0(next chunk) in the middle, then at the end b1(next chunk) and last the halo of chunk ch+3, which is first
+  // awaited a whole iteration later (store_halo at the end of iteration ch+1).
+  float4 b0[4][2], b1[4][2], a[4];
+  load_halo(0);
+  store_halo(Hs);
+  if (nchunks > 1) load_halo(KC);
+  __syncthreads();
+  transform(Hs, Vs);
+  if (nchunks > 1) store_halo(Hs + HALO_F);
+  load_b(0, 0, b0);
+  load_b(0, 1, b1);
+  if (nchunks > 2) load_halo(2 * KC);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* Vc = Vs + (ch & 1) * V_F;
+    load_a(Vc, 0, a);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch + 1 < nchunks) transform(Hs + ((ch + 1) & 1) * HALO_F, Vs + ((ch + 1) & 1) * V_F);
+    load_a(Vc, 1, a);
+    if (ch + 1 < nchunks) load_b(ch + 1, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch + 2 < nchunks) store_halo(Hs + (ch & 1) * HALO_F);   // chunk ch+2; this stage was last read by transform(ch)
+    if (ch + 1 < nchunks) load_b(ch + 1, 1, b1);
+    if (ch + 3 < nchunks) load_halo((ch + 3) * KC);
+    __syncthreads();
+  }
+
+  // output transform: as in the 4-wave kernel, one exchange area per co half: X[half][row][c][reg][lane]
+  float* X = dsmem + half * 8192;
+  const int img_bytes = p.H * p.W * p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+  const bool relu = p.act != 0;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+      X[((xr * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
+      X[((xr * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
+    }
+    __syncthreads();
+    const int co = n0 + nt * 32 + li;
+    const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = xr * 4 + rr;
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int py = oy0 + 2 * (tile / TXN), px = ox0 + 2 * (tile % TXN);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float r0 = X[((0 * 2 + c) * 16 + r) * 64 + lane], r1 = X[((1 * 2 + c) * 16 + r) * 64 + lane];
+        const float r2 = X[((2 * 2 + c) * 16 + r) * 64 + lane], r3 = X[((3 * 2 + c) * 16 + r) * 64 + lane];
+        const float y0 = r0 + r1 + r2 + bv, y1 = r1 - r2 - r3 + bv;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          const int oy = py + a2, ox = px + c;
+          const unsigned off = (oy < p.H && ox < p.W && co < p.Cout) ? (unsigned)(((oy * p.W + ox) * p.Cout + co) * 4) : 0x7FFFFFF0u;
+          float v = a2 == 0 ? y0 : y1;
+          if (p.residual) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, off, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(v, 0.f) : v), yrsrc, off, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // U[xi = 4a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles
 __global__ void conv3x3_pack_wino_kernel(const float* __restrict__ w, int Cout, int Cin,
                                          float* __restrict__ fwd, int CinP_f, int CoutP_f,
@@ -291,7 +477,18 @@ int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const f
   p.tiles_x = ceil_div(W, TW); p.tiles_y = ceil_div(H, TH); p.act = act;
   const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino: too many tiles");
-  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  static const bool no8 = getenv("ODVAE_WINO_4WAVE") != nullptr;
+  if (Cout % BN8 == 0 && !no8) {
+    const size_t smem = (size_t)(2 * HALO_F + 2 * V_F) * sizeof(float);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      odvae_set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return ODVAE_ERR_HIP;
+    }
+    hipLaunchKernelGGL(conv3x3_wino8_kernel, dim3((unsigned)sp, p.CoutP / BN8), dim3(512), smem, static_cast<hipStream_t>(stream), p);
+  } else {
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  }
   ODVAE_LAUNCH_CHECK("conv3x3_wino");
   return ODVAE_OK;
 }
