@@ -7,7 +7,7 @@ import glob
 import json
 import sys
 
-KERNEL = "conv3x3_kernel_v2<0, 32, 2, 2, 2, 2, 1>"
+KERNEL = "conv3x3_wino8_kernel"   # dominant kernel of the step (override: 4th argument)
 
 
 def per_launch(d, counter):
@@ -30,4 +30,6 @@ def main(fetch_dir, write_dir, out):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 4:
+        KERNEL = sys.argv[4]
     main(*sys.argv[1:4])
