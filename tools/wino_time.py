@@ -1,5 +1,6 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+"""Time the default 3x3 conv forward on two layer shapes (used for rocprofv3 --pmc passes and ablation builds)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from odvae_amd import ops
 dev = "cuda:0"
 for (b, cin, cout, h) in [(32,128,128,256),(32,256,256,64)]:
