@@ -333,7 +333,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   // b0(next chunk) in the middle, then at the end b1(next chunk) and last the halo of chunk ch+3, which is first
   // awaited a whole iteration later (store_halo at the end of iteration ch+1).
   // one set of weight fragments: the loads of the next group are issued right behind the MFMAs that read the current
-  // ones (64 registers less than double-buffering them: no scratch spills; the other wave of the SIMD covers the latency)
+  // ones (64 registers less than double-buffering them: no scratch spills; the other wave of the SIMD covers the latency).
+  // No sched_barrier pins here: hipcc's own interleaving of the transform with the MFMAs measured 2-3 % faster.
   float4 b[4][2], a[4];
   load_halo(0);
   store_halo(Hs);
@@ -347,15 +348,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* Vc = Vs + (ch & 1) * V_F;
     load_a(Vc, 0, a);
-    __builtin_amdgcn_sched_barrier(0);
     mma(a, b);
-    __builtin_amdgcn_sched_barrier(0);
     load_b(ch, 1, b);
     if (ch + 1 < nchunks) transform(Hs + ((ch + 1) & 1) * HALO_F, Vs + ((ch + 1) & 1) * V_F);
     load_a(Vc, 1, a);
-    __builtin_amdgcn_sched_barrier(0);
     mma(a, b);
-    __builtin_amdgcn_sched_barrier(0);
     if (ch + 1 < nchunks) load_b(ch + 1, 0, b);
     if (ch + 2 < nchunks) store_halo(Hs + (ch & 1) * HALO_F);   // chunk ch+2; this stage was last read by transform(ch)
     if (ch + 3 < nchunks) load_halo((ch + 3) * KC);
