@@ -143,12 +143,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
 
   // Two barriers per chunk: the halo is double-buffered in LDS (chunk c+1 is stored while chunk c is multiplied), V is
   // single-buffered (transform -> barrier -> MFMAs -> barrier).  The two blocks of a CU run these phases out of step, so
-  // one block's transform (VALU + LDS) hides under the other's MFMAs.  Weight fragments are prefetched one group ahead
-  // (across the chunk boundary too), A fragments of group 1 behind the MFMAs of group 0.
+  // one block's transform (VALU + LDS) hides under the other's MFMAs.
   static_assert(KC == 16, "two k-groups per chunk");
-  float4 b0[4][2], b1[4][2], a[4];
+  float4 b[4][2], a[4];   // one set of weight fragments, reloaded right behind the MFMAs that read it (see the 8-wave kernel)
   load_halo(0);
-  load_b(0, 0, b0);
+  load_b(0, 0, b);
   store_halo(Hs);
   if (nchunks > 1) load_halo(KC);
   __syncthreads();
@@ -160,15 +159,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
       if (ch + 2 < nchunks) load_halo((ch + 2) * KC);
     }
     load_a(0, a);
-    load_b(ch, 1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a, b0);
-    __builtin_amdgcn_sched_barrier(0);
+    mma(a, b);
+    load_b(ch, 1, b);
     load_a(1, a);
-    if (ch + 1 < nchunks) load_b(ch + 1, 0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a, b1);
-    __builtin_amdgcn_sched_barrier(0);
+    mma(a, b);
+    if (ch + 1 < nchunks) load_b(ch + 1, 0, b);
     __syncthreads();
   }
 
