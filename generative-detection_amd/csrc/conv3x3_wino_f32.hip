@@ -396,34 +396,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   }
 }
 
-// U[xi = 4a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles
+// U[xi = 4a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles.
+// One thread per (co, ci) pair: reads the nine weights once and writes its 16 (+16) pack entries; padding entries of the
+// packs are zero-filled by the launcher (hipMemsetAsync) beforehand.
 __global__ void conv3x3_pack_wino_kernel(const float* __restrict__ w, int Cout, int Cin,
                                          float* __restrict__ fwd, int CinP_f, int CoutP_f,
                                          float* __restrict__ dgr, int CoutP_d, int CinP_d) {
-  const int64_t nf = fwd ? (int64_t)16 * CinP_f * CoutP_f : 0;
-  const int64_t nd = dgr ? (int64_t)16 * CoutP_d * CinP_d : 0;
-  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const bool is_f = idx < nf;
-    int64_t r = is_f ? idx : idx - nf;
-    const int outP = is_f ? CoutP_f : CinP_d, redP = is_f ? CinP_f : CoutP_d;
-    const int j = r & 3; r >>= 2;
-    const int o = (int)(r % outP); r /= outP;
-    const int q = (int)(r % (redP / 4)); const int xi = (int)(r / (redP / 4));
-    const int red = 4 * q + j;
-    const int co = is_f ? o : red, ci = is_f ? red : o;
-    float u = 0.f;
-    if (co < Cout && ci < Cin) {
-      const float* g = w + ((int64_t)co * Cin + ci) * 9;
-      const int a = xi >> 2, b = xi & 3;
-      for (int kh = 0; kh < 3; ++kh)
-        for (int kw = 0; kw < 3; ++kw) {
-          const float gv = is_f ? g[kh * 3 + kw] : g[(2 - kh) * 3 + (2 - kw)];
-          u += G[a][kh] * gv * G[b][kw];
-        }
+  const int64_t pairs = (int64_t)Cout * Cin;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (int64_t)gridDim.x * blockDim.x) {
+    // co fastest: the forward pack is co-contiguous, so a wavefront writes 64 consecutive float4 slots' lanes
+    const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
+    const float* g = w + ((int64_t)co * Cin + ci) * 9;
+    float gg[3][3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gg[k / 3][k % 3] = g[k];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float* dst = pass == 0 ? fwd : dgr;
+      if (!dst) continue;
+      // G x: rows (x0, (x0+x1+x2)/2, (x0-x1+x2)/2, x2)
+      float t[4][3], u[4][4];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float x0 = pass == 0 ? gg[0][c] : gg[2][2 - c], x1 = pass == 0 ? gg[1][c] : gg[1][2 - c],
+                    x2 = pass == 0 ? gg[2][c] : gg[0][2 - c];
+        t[0][c] = x0; t[1][c] = 0.5f * (x0 + x1 + x2); t[2][c] = 0.5f * (x0 - x1 + x2); t[3][c] = x2;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        u[a][0] = t[a][0]; u[a][1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]); u[a][2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        u[a][3] = t[a][2];
+      }
+      const int red = pass == 0 ? ci : co, out = pass == 0 ? co : ci;
+      const int redP = pass == 0 ? CinP_f : CoutP_d, outP = pass == 0 ? CoutP_f : CinP_d;
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi)
+        dst[(((int64_t)xi * (redP / 4) + red / 4) * outP + out) * 4 + (red & 3)] = u[xi >> 2][xi & 3];
     }
-    (is_f ? fwd : dgr)[is_f ? idx : idx - nf] = u;
   }
 }
 
@@ -446,8 +455,16 @@ int odvae_conv3x3_pack_wino_f32(const float* w, int Cout, int Cin, float* fwd_pa
   const int CoutP_d = odvae_conv3x3_wino_reduce_pad(Cout), CinP_d = odvae_conv3x3_wino_out_pad(Cin);
   const int64_t total = (fwd_pack ? (int64_t)16 * CinP_f * CoutP_f : 0) + (dgrad_pack ? (int64_t)16 * CoutP_d * CinP_d : 0);
   if (total == 0) return ODVAE_OK;
-  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 2048);
-  hipLaunchKernelGGL(conv3x3_pack_wino_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // padded rows / columns must read as zero; only shapes with padding need the fill
+  if (fwd_pack && (CinP_f != Cin || CoutP_f != Cout)) {
+    if (hipMemsetAsync(fwd_pack, 0, (size_t)16 * CinP_f * CoutP_f * sizeof(float), st) != hipSuccess) { odvae_set_error("conv3x3_pack_wino: memset failed"); return ODVAE_ERR_HIP; }
+  }
+  if (dgrad_pack && (CoutP_d != Cout || CinP_d != Cin)) {
+    if (hipMemsetAsync(dgrad_pack, 0, (size_t)16 * CoutP_d * CinP_d * sizeof(float), st) != hipSuccess) { odvae_set_error("conv3x3_pack_wino: memset failed"); return ODVAE_ERR_HIP; }
+  }
+  const int blocks = (int)std::min<int64_t>(ceil_div64((int64_t)Cout * Cin, 256), 2048);
+  hipLaunchKernelGGL(conv3x3_pack_wino_kernel, dim3(blocks), dim3(256), 0, st,
                      w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d);
   ODVAE_LAUNCH_CHECK("conv3x3_pack_wino");
   return ODVAE_OK;
