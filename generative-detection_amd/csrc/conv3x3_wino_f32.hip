@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
   const int img_bytes = p.H * p.W * p.Cout * 4;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+      const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, p.residual ? img_bytes : 0, 0x00020000);
   const bool relu = p.act != 0;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -185,28 +185,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
       X[((wave * 2 + 0) * 16 + r) * 64 + lane] = m0 + m1 + m2;
       X[((wave * 2 + 1) * 16 + r) * 64 + lane] = m1 - m2 - m3;
     }
-    __syncthreads();
-    // wave w finishes registers r = 4w .. 4w+3 (tiles (r&3) + 8(r>>2) + 4h): 4 output pixels each
+    // wave w finishes registers r = 4w .. 4w+3 (tiles (r&3) + 8(r>>2) + 4h): 4 output pixels each.  Bias + residual are
+    // fetched before the exchange barrier; the stores follow with no load in between.
     const int co = n0 + nt * 32 + li;
     const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    unsigned off[4][2][2];
+    float seed[4][2][2];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int r = wave * 4 + rr;
       const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
       const int py = oy0 + 2 * (tile / TXN), px = ox0 + 2 * (tile % TXN);
 #pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          const int oy = py + a2, ox = px + c;
+          off[rr][c][a2] = (oy < p.H && ox < p.W && co < p.Cout) ? (unsigned)(((oy * p.W + ox) * p.Cout + co) * 4) : 0x7FFFFFF0u;
+          seed[rr][c][a2] = bv + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, off[rr][c][a2], 0, 0));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = wave * 4 + rr;
+#pragma unroll
       for (int c = 0; c < 2; ++c) {
         const float r0 = X[((0 * 2 + c) * 16 + r) * 64 + lane], r1 = X[((1 * 2 + c) * 16 + r) * 64 + lane];
         const float r2 = X[((2 * 2 + c) * 16 + r) * 64 + lane], r3 = X[((3 * 2 + c) * 16 + r) * 64 + lane];
-        const float y0 = r0 + r1 + r2 + bv, y1 = r1 - r2 - r3 + bv;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const int oy = py + a, ox = px + c;
-          const unsigned off = (oy < p.H && ox < p.W && co < p.Cout) ? (unsigned)(((oy * p.W + ox) * p.Cout + co) * 4) : 0x7FFFFFF0u;
-          float v = a == 0 ? y0 : y1;
-          if (p.residual) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, off, 0, 0));
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(v, 0.f) : v), yrsrc, off, 0, 0);
-        }
+        const float y0 = r0 + r1 + r2 + seed[rr][c][0], y1 = r1 - r2 - r3 + seed[rr][c][1];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(y0, 0.f) : y0), yrsrc, off[rr][c][0], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(y1, 0.f) : y1), yrsrc, off[rr][c][1], 0, 0);
       }
     }
     __syncthreads();   // X is rewritten for the next co-tile
