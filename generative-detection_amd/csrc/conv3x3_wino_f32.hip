@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   constexpr int HALO_F4 = HH * HW * (KC / 4);           // 720
   constexpr int HALO_IT = (HALO_F4 + 511) / 512;        // 2
   float4 hreg[HALO_IT];
-  auto load_halo = [&](int c0) {
+  auto load_halo_to = [&](int c0, float4 (&hr)[HALO_IT]) {
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
       const int f = tid + 512 * i;
@@ -260,16 +260,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
       const bool ok = f < HALO_F4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
       const unsigned voff = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + c) * 4) : 0x7FFFFFF0u;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
-      hreg[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      hr[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
-  auto store_halo = [&](float* Hd) {
+  auto store_halo_from = [&](float* Hd, const float4 (&hr)[HALO_IT]) {
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
       const int f = tid + 512 * i;
-      if (f < HALO_F4) *reinterpret_cast<float4*>(Hd + (f >> 2) * HS + 4 * (f & 3)) = hreg[i];
+      if (f < HALO_F4) *reinterpret_cast<float4*>(Hd + (f >> 2) * HS + 4 * (f & 3)) = hr[i];
     }
   };
+  auto load_halo = [&](int c0) { load_halo_to(c0, hreg); };
+  auto store_halo = [&](float* Hd) { store_halo_from(Hd, hreg); };
   auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
   auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
   // thread = (tile, channel quad, row pair rp, column pair cp): rows {2rp, 2rp+1} x columns {2cp, 2cp+1} of V
@@ -340,14 +342,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   // ones (64 registers less than double-buffering them: no scratch spills; the other wave of the SIMD covers the latency).
   // No sched_barrier pins here: hipcc's own interleaving of the transform with the MFMAs measured 2-3 % faster.
   float4 b[4][2], a[4];
-  load_halo(0);
-  store_halo(Hs);
-  if (nchunks > 1) load_halo(KC);
+  {   // prologue: the halos of chunks 0 and 1 are requested together (one HBM latency, not two in a row)
+    float4 h1[HALO_IT];
+    load_halo(0);
+    if (nchunks > 1) load_halo_to(KC, h1);
+    load_b(0, 0, b);
+    store_halo(Hs);
+    if (nchunks > 1) store_halo_from(Hs + HALO_F, h1);
+    if (nchunks > 2) load_halo(2 * KC);
+  }
   __syncthreads();
   transform(Hs, Vs);
-  if (nchunks > 1) store_halo(Hs + HALO_F);
-  load_b(0, 0, b);
-  if (nchunks > 2) load_halo(2 * KC);
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* Vc = Vs + (ch & 1) * V_F;
