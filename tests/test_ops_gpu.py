@@ -129,6 +129,33 @@ def test_conv3x3_fwd_bwd(hip_lib, mode, n, cin, cout, h, w):
     close(resd.grad, resr.grad, 1e-6, "conv dres")
 
 
+@pytest.mark.parametrize("case", [(0, 2, 32, 64, 24, 16), (0, 1, 64, 160, 20, 12), (0, 1, 256, 256, 8, 8)])
+def test_conv3x3_direct_kernel_still_matches(hip_lib, monkeypatch, case):
+    """ODVAE_CONV_WINOGRAD=0: the direct implicit-GEMM kernel (the in-tree reference of the Winograd path) on the shapes
+    that Winograd serves by default."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD", False)
+    test_conv3x3_fwd_bwd(hip_lib, *case)
+
+
+def test_winograd_and_direct_kernels_agree(hip_lib, monkeypatch):
+    """Same f32 inputs through both kernels: forward and data gradient agree to a few 1e-6 of max|y| (summation order)."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 128, 32, 48, generator=g).to(dev())
+    w = (torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(9 * 128)).to(dev())
+    gy = torch.randn(2, 128, 32, 48, generator=g).to(dev())
+    outs = []
+    for wino in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", wino)
+        xd = x.clone().requires_grad_(True)
+        y = ops.conv3x3(xd, w.clone().requires_grad_(True))
+        y.backward(gy)
+        outs.append((y.detach(), xd.grad))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
 def test_upsample_conv_dense_form_still_matches(hip_lib, monkeypatch):
     """ODVAE_UPCONV_DENSE=1 keeps mode 2 (dense 3x3 at 2x resolution; data gradient = mode 0 + 2x2 sum-pool) for A/B."""
     from odvae_amd import ops
