@@ -7,7 +7,8 @@ optimizer 1 skipped), VAE phase.  One process per GPU; N > 1 is
 and shards the minibatch (weak scaling) with the bucketed RCCL all-reduce of generative-detection_amd/parallel.py.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every launch of the dominant
-kernel (the 128x128-tile 3x3 implicit-GEMM convolution, forward + data-gradient) during the timed steps;
+kernel (the stride-1 3x3 convolution, forward + data-gradient: fused Winograd F(2x2,3x3), or the direct implicit-GEMM kernel
+under ODVAE_CONV_WINOGRAD=0) during the timed steps;
 `cpu_baseline` times the CPU oracle (a port: the reference itself cannot be imported) on a bounded sample.
 """
 import argparse
@@ -33,6 +34,8 @@ def parse():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--gan", action="store_true",
                     help="BASELINE.json configs[3]: PatchGAN discriminator + LPIPS-style loss, both optimizers per batch")
+    ap.add_argument("--ckpt-decoder", action="store_true",
+                    help="BASELINE.json configs[4]: activation-checkpointed Decoder (each up level / mid block is recomputed in backward)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL with world size 1 and run the bucketed reducer anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,6 +112,8 @@ def main():
     gan = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if args.gan else {}
     model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gan).to(dev)
     model.train()
+    if args.ckpt_decoder:
+        model.decoder.activation_checkpoint = True
     # steady state: past the very first optimizer step, whose total holds the pose terms only (`global_step >
     # encoder_pretrain_steps`, contperceptual.py:307) and would skip the decoder's backward pass -- every timed step does the
     # full forward + backward + optimizer work even with --warmup 0
@@ -149,7 +154,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            "metric": "VAE train images/s (fwd+bwd+opt) at 256x256 z=16x16x16",
+            "metric": "VAE train images/s (fwd+bwd+opt) at %dx%d z=%dx%dx16" % (args.res, args.res, lat, lat),
             "value": args.batch * world * args.steps / elapsed,
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -157,14 +162,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
                        % (args.res, args.res, args.batch,
-                          "PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
-                          else "rec+KL only (discriminator off, optimizer 0)"),
+                          ("PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
+                           else "rec+KL only (discriminator off, optimizer 0)")
+                          + (", activation-checkpointed Decoder" if args.ckpt_decoder else "")),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         }
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
             tpath = os.path.join(ROOT, "profiles", "r01_conv3x3_traffic.json")
-            if os.path.exists(tpath) and not args.gan and args.batch == 32 and args.res == 256:
+            if os.path.exists(tpath) and not args.gan and args.batch == 32 and args.res == 256 and not args.ckpt_decoder:
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             wino = ops.WINOGRAD
             out["roofline"] = {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -89,6 +89,8 @@ CONV_CASES = [
     (0, 2, 3, 160, 8, 48),      # thin-side weight gradient, channel tiles past Cb
     (0, 1, 160, 2, 12, 16),     # thin output side with 2 channels
     (0, 3, 1, 64, 5, 16),       # thin input side with 1 channel
+    (0, 1, 64, 128, 20, 12),    # 8-wave Winograd kernel, ragged 8x16 pixel tiles on both axes
+    (0, 2, 36, 256, 6, 10),     # 8-wave Winograd kernel, Cin padded to the 16-channel chunk, two co blocks
     (1, 2, 32, 32, 16, 32),
     (1, 1, 128, 128, 8, 8),
     (2, 2, 32, 32, 8, 16),
