@@ -100,21 +100,23 @@ def check_step(model, ref, global_step, height, latent_hw):
         assert ref_params["decoder.conv_in.weight"].grad.abs().max().item() > 0
 
 
-def test_gan_lpips_training_batch_matches_oracle(hip_lib):
-    """BASELINE.json configs[3] in miniature: PatchGAN + LPIPS-style loss, both optimizers (generator step with the
-    adaptive weight from two partial backward passes, then the discriminator step), two batches."""
+@pytest.mark.parametrize("ch,height,latent_hw", [(32, 64, 4), (None, 256, 16)], ids=["narrow-64", "headline-256"])
+def test_gan_lpips_training_batch_matches_oracle(hip_lib, ch, height, latent_hw):
+    """BASELINE.json configs[3]: PatchGAN + LPIPS-style loss, both optimizers (generator step with the adaptive weight
+    from two partial backward passes, then the discriminator step), two batches; in miniature and ("headline-256") on
+    the benchmark's own network and resolution."""
     from odvae_amd import synthetic
     from odvae_amd.trainer import Trainer
     from oracle.autoencoder import train_batch
-    model, ref = build_pair(perceptual_weight=1.0, disc_factor=1.0)
+    model, ref = build_pair(perceptual_weight=1.0, disc_factor=1.0, ch=ch, latent_hw=latent_hw)
     model.train(); ref.train()
     model.loss.perceptual_loss.eval(); ref.loss.perceptual_loss.eval()
     trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1))
     ref_opts = ref.configure_optimizers()
     for step in range(2):
-        batch = synthetic.make_batch(2, 64, seed=300 + step)
-        noises = {0: synthetic.make_noise(2, 4, dropout_p=0.7, seed=400 + 2 * step),
-                  1: synthetic.make_noise(2, 4, dropout_p=0.7, seed=401 + 2 * step)}
+        batch = synthetic.make_batch(2, height, seed=300 + step)
+        noises = {0: synthetic.make_noise(2, latent_hw, dropout_p=0.7, seed=400 + 2 * step),
+                  1: synthetic.make_noise(2, latent_hw, dropout_p=0.7, seed=401 + 2 * step)}
         got = []
         for idx in (0, 1):   # one optimizer at a time so each forward sees its own injected noise
             model.injected_noise = noises[idx]
