@@ -1,0 +1,272 @@
+// Weight gradient of the stride-1 3x3 convolution in the Winograd F(2x2, 3x3) domain, fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Forward: Y = A^T [ (G g G^T) .* (B^T d B) ] A per 2x2 output tile.  With V = B^T d B (the forward input transform of
+// the 4x4 input patch) and dM = A dY A^T (the 2x2 output-gradient tile carried into the 4x4 domain),
+//     dU[xi][ci][co] = sum over tiles  V[xi][tile][ci] * dM[xi][tile][co]        (16 independent products, K = tiles)
+//     dg = G^T dU G                                                              (once, in the slab reduction)
+// i.e. 16 instead of 36 multiply-adds per tile and (ci, co): autograd's `conv2d` weight gradient
+// ([UPSTREAM] ldm/modules/diffusionmodules/model.py ResnetBlock.conv1/conv2, Encoder/Decoder conv layers; called from
+// src/modules/autoencodermodules/feat_encoder.py:2, feat_decoder.py:2) in 0.44x the MFMA work of conv3x3_wgrad_f32.hip.
+//
+// Block = 8 waves, one ROW r of the 4x4 domain (xi = 4r + c, c = 0..3) x 128 ci x 128 co = 128 accumulator registers per
+// wave (wave = 32-ci group x 64-co half), over a contiguous split of the tiles.  A block transforms only its own row:
+// row r of B^T d needs two of the four patch rows, row r of A dY one or both tile rows -- no transform work is repeated
+// across the four row blocks.  Per chunk of 16 tiles every thread fetches one (tile, channel quad) of x and of dy
+// straight from HBM into registers (a wavefront reads whole 512-byte channel rows), transforms it and writes V and dM
+// `[c][tile][128 + 4]` into LDS (double-buffered, 132 KB); the MFMA phase reads scalar fragments (lane = channel, the
+// two k lanes = two tiles): 64 MFMAs per wave and barrier.  The fetch of chunk k+2 is in flight during the MFMAs of
+// chunk k.  Each block writes its partial dU slab; the reduction sums the slabs in a fixed order (deterministic),
+// applies G^T . G and writes OIHW.  The bias gradient rides along: dM[xi = (1,1)] is the sum of the tile's four dy pixels.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int CT = 16;               // tiles per chunk
+constexpr int RS = 128 + 4;          // LDS row stride in floats ([c][tile][channel])
+constexpr int OPF = 4 * CT * RS;     // floats per operand and stage (8 448)
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+struct WgwParams {
+  const float* x; const float* dy; float* slabs; float* bias_part;
+  int N, H, W, Cin, Cout, TY, TX;
+  int total_tiles, total_chunks, chunks_per_split, nsplit;
+};
+
+__device__ __forceinline__ float4 f4(u32x4 v) {
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float4 f4lin(float a, float4 x, float b, float4 y) {
+  return make_float4(a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z, a * x.w + b * y.w);
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // stage s: V at s*2*OPF, dM at s*2*OPF + OPF
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cig = wave & 3, coh = wave >> 2;
+  const int li = lane & 31, h = lane >> 5;
+  const int r = blockIdx.x & 3, split = blockIdx.x >> 2;
+  const int cib = blockIdx.y, cob = blockIdx.z;
+  // row r of B^T d = sa * d[ra] + sb * d[rb];  row r of A dY = ya * dy[0] + yb * dy[1]
+  const int ra = r == 0 ? 0 : 1, rb = r == 3 ? 3 : 2;
+  const float sa = r == 2 ? -1.f : 1.f, sb = (r == 0 || r == 3) ? -1.f : 1.f;
+  const float ya = r == 3 ? 0.f : 1.f, yb = r == 0 ? 0.f : (r == 1 ? 1.f : -1.f);
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (unsigned)((int64_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.dy), 0, (unsigned)((int64_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
+
+  const int st = tid >> 5, sq = tid & 31;     // staging role: tile of the chunk, channel quad
+  float4 xr[2][4], yr[2][2];
+  auto fetch = [&](int chunk) {
+    const int tl = chunk * CT + st;
+    const bool valid = tl < p.total_tiles;
+    const int per_img = p.TY * p.TX;
+    const int n = tl / per_img, rem = tl - n * per_img;
+    const int ty = rem / p.TX, tx = rem - ty * p.TX;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int iy = 2 * ty - 1 + (rr ? rb : ra);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ix = 2 * tx - 1 + c;
+        const bool ok = valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const unsigned off = ok ? (unsigned)((((int64_t)(n * p.H + iy) * p.W + ix) * p.Cin + cib * 128 + 4 * sq) * 4) : OOB;
+        xr[rr][c] = f4(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const bool used = valid && (rr ? yb : ya) != 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned off = used ? (unsigned)((((int64_t)(n * p.H + 2 * ty + rr) * p.W + 2 * tx + j) * p.Cout + cob * 128 + 4 * sq) * 4) : OOB;
+        yr[rr][j] = f4(__builtin_amdgcn_raw_buffer_load_b128(yrsrc, off, 0, 0));
+      }
+    }
+  };
+  float4 bias_acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto stage = [&](float* V, float* M) {
+    float4 w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = f4lin(sa, xr[0][c], sb, xr[1][c]);
+    float* vd = V + st * RS + 4 * sq;
+    *reinterpret_cast<float4*>(vd + 0 * CT * RS) = f4sub(w[0], w[2]);
+    *reinterpret_cast<float4*>(vd + 1 * CT * RS) = f4add(w[1], w[2]);
+    *reinterpret_cast<float4*>(vd + 2 * CT * RS) = f4sub(w[2], w[1]);
+    *reinterpret_cast<float4*>(vd + 3 * CT * RS) = f4sub(w[1], w[3]);
+    const float4 z0 = f4lin(ya, yr[0][0], yb, yr[1][0]), z1 = f4lin(ya, yr[0][1], yb, yr[1][1]);
+    const float4 m1 = f4add(z0, z1);
+    float* md = M + st * RS + 4 * sq;
+    *reinterpret_cast<float4*>(md + 0 * CT * RS) = z0;
+    *reinterpret_cast<float4*>(md + 1 * CT * RS) = m1;
+    *reinterpret_cast<float4*>(md + 2 * CT * RS) = f4sub(z0, z1);
+    *reinterpret_cast<float4*>(md + 3 * CT * RS) = make_float4(-z1.x, -z1.y, -z1.z, -z1.w);
+    bias_acc = f4add(bias_acc, m1);      // meaningful in the r = 1 blocks: dy00 + dy01 + dy10 + dy11
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[c][nt][q] = 0.f;
+
+  auto mma = [&](const float* V, const float* M) {
+    const float* va = V + h * RS + cig * 32 + li;
+    const float* mb = M + h * RS + coh * 64 + li;
+#pragma unroll
+    for (int t2 = 0; t2 < CT / 2; ++t2) {
+      float a[4], b[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        a[c] = va[(c * CT + 2 * t2) * RS];
+        b[c][0] = mb[(c * CT + 2 * t2) * RS];
+        b[c][1] = mb[(c * CT + 2 * t2) * RS + 32];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[c][0] = mfma32(a[c], b[c][0], acc[c][0]);
+        acc[c][1] = mfma32(a[c], b[c][1], acc[c][1]);
+      }
+    }
+  };
+
+  const int chunk0 = split * p.chunks_per_split;
+  const int nch = min(p.chunks_per_split, p.total_chunks - chunk0);   // >= 1 by construction of nsplit
+  fetch(chunk0);
+  stage(dsm, dsm + OPF);
+  if (nch > 1) fetch(chunk0 + 1);
+  __syncthreads();
+  for (int k = 0; k < nch; ++k) {
+    float* cur = dsm + (k & 1) * 2 * OPF;
+    float* nxt = dsm + ((k + 1) & 1) * 2 * OPF;
+    if (k + 1 < nch) stage(nxt, nxt + OPF);
+    if (k + 2 < nch) fetch(chunk0 + k + 2);
+    mma(cur, cur + OPF);
+    __syncthreads();
+  }
+
+  // partial dU of this block: slabs[split][xi = 4r + c][ci][co]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float* sl = p.slabs + ((int64_t)(split * 16 + 4 * r + c) * p.Cin + cib * 128 + cig * 32) * p.Cout + cob * 128 + coh * 64 + li;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sl[(int64_t)acc_row(q, lane) * p.Cout + nt * 32] = acc[c][nt][q];
+  }
+  if (r == 1 && cib == 0 && p.bias_part) {   // block-uniform
+    *reinterpret_cast<float4*>(dsm + st * 128 + 4 * sq) = bias_acc;
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) s += dsm[t * 128 + tid];
+      p.bias_part[(int64_t)split * p.Cout + cob * 128 + tid] = s;
+    }
+  }
+}
+
+// dw[co][ci][a][b] = (G^T (sum over splits of dU) G)[a][b];  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ void conv3x3_wgrad_wino_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_part,
+                                                 int nsplit, int Cin, int Cout, float* __restrict__ dw, float* __restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < Cin * Cout) {
+    const int co = idx % Cout, ci = idx / Cout;
+    float u[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[xi] = 0.f;
+    for (int s = 0; s < nsplit; ++s)
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) u[xi] += slabs[((int64_t)(s * 16 + xi) * Cin + ci) * Cout + co];
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float hs = 0.5f * (u[4 + j] + u[8 + j]), hd = 0.5f * (u[4 + j] - u[8 + j]);
+      t[0][j] = u[j] + hs; t[1][j] = hd; t[2][j] = hs + u[12 + j];
+    }
+    float* o = dw + ((int64_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float hs = 0.5f * (t[a][1] + t[a][2]), hd = 0.5f * (t[a][1] - t[a][2]);
+      o[a * 3 + 0] = t[a][0] + hs; o[a * 3 + 1] = hd; o[a * 3 + 2] = hs + t[a][3];
+    }
+  }
+  if (db && idx < Cout) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += bias_part[(int64_t)k * Cout + idx];
+    db[idx] = s;
+  }
+}
+
+void plan(int N, int H, int W, int Cin, int Cout, WgwParams& p) {
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.TY = H / 2; p.TX = W / 2;
+  p.total_tiles = N * p.TY * p.TX;
+  p.total_chunks = ceil_div(p.total_tiles, CT);
+  static const int target = getenv("ODVAE_WGRAD_WINO_BLOCKS") ? atoi(getenv("ODVAE_WGRAD_WINO_BLOCKS")) : 256;
+  const int base = 4 * (Cin / 128) * (Cout / 128);
+  int ns = std::max(1, std::min(target / base, p.total_chunks));
+  p.chunks_per_split = ceil_div(p.total_chunks, ns);
+  p.nsplit = ceil_div(p.total_chunks, p.chunks_per_split);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when the Winograd-domain weight gradient serves this shape (otherwise use odvae_conv3x3_wgrad_f32)
+int odvae_conv3x3_wgrad_wino_supported(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || Cin <= 0 || Cout <= 0 || Cin % 128 || Cout % 128) return 0;
+  const int64_t px = (int64_t)N * H * W;
+  if (px * Cin * 4 >= (int64_t)OOB || px * Cout * 4 >= (int64_t)OOB || px / 4 >= (1ll << 30)) return 0;
+  return 1;
+}
+
+size_t odvae_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  if (!odvae_conv3x3_wgrad_wino_supported(N, H, W, Cin, Cout)) return 0;
+  WgwParams p; plan(N, H, W, Cin, Cout, p);
+  return ((size_t)p.nsplit * 16 * Cin * Cout + (size_t)p.nsplit * Cout) * sizeof(float);
+}
+
+// x [N][H][W][Cin], dy [N][H][W][Cout] (NHWC f32) -> dw OIHW [Cout][Cin][3][3] (overwritten), dbias [Cout] or NULL.
+// Replaces autograd's weight/bias gradient of F.conv2d(x, w, b, stride=1, padding=1).
+int odvae_conv3x3_wgrad_wino_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout,
+                                 float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  ODVAE_CHECK_ARG(x && dy && dw, "conv3x3_wgrad_wino: null operand");
+  ODVAE_CHECK_ARG(odvae_conv3x3_wgrad_wino_supported(N, H, W, Cin, Cout),
+                  "conv3x3_wgrad_wino: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (even H, W; channels in multiples of 128; "
+                  "tensors below 4 GiB)", N, H, W, Cin, Cout);
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv3x3_wgrad_wino: x/dy must be 16-byte aligned");
+  WgwParams p; plan(N, H, W, Cin, Cout, p);
+  const size_t need = odvae_conv3x3_wgrad_wino_workspace_bytes(N, H, W, Cin, Cout);
+  if (!workspace || workspace_bytes < need) {
+    odvae_set_error("conv3x3_wgrad_wino: workspace %zu < %zu bytes", workspace_bytes, need);
+    return ODVAE_ERR_WORKSPACE;
+  }
+  p.x = x; p.dy = dy;
+  p.slabs = static_cast<float*>(workspace);
+  p.bias_part = dbias ? p.slabs + (size_t)p.nsplit * 16 * Cin * Cout : nullptr;
+  const size_t smem = (size_t)4 * OPF * sizeof(float);
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_wino_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) {
+    odvae_set_error("conv3x3_wgrad_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return ODVAE_ERR_HIP;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(4 * p.nsplit, Cin / 128, Cout / 128), dim3(512), smem, s, p);
+  ODVAE_LAUNCH_CHECK("conv3x3_wgrad_wino");
+  const int pairs = Cin * Cout;
+  hipLaunchKernelGGL(conv3x3_wgrad_wino_reduce_kernel, dim3(ceil_div(pairs, 256)), dim3(256), 0, s,
+                     p.slabs, p.bias_part, p.nsplit, Cin, Cout, dw, dbias);
+  ODVAE_LAUNCH_CHECK("conv3x3_wgrad_wino_reduce");
+  return ODVAE_OK;
+}
+
+}  // extern "C"

@@ -34,6 +34,9 @@ PROTOTYPES = {
     "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "odvae_conv3x3_wgrad_wino_supported": (_I, [_I, _I, _I, _I, _I]),
+    "odvae_conv3x3_wgrad_wino_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "odvae_conv3x3_wgrad_wino_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "odvae_groupnorm_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),

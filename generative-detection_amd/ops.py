@@ -171,6 +171,9 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
 # Stride-1 3x3 convs by Winograd F(2x2, 3x3) (conv3x3_wino_f32.hip) when the shape allows; ODVAE_CONV_WINOGRAD=0 keeps
 # the direct implicit-GEMM kernel everywhere
 WINOGRAD = os.environ.get("ODVAE_CONV_WINOGRAD", "1") != "0"
+# Weight gradient of those convs in the Winograd domain (conv3x3_wgrad_wino_f32.hip) where the shape allows (even H, W,
+# channel counts in multiples of 128); ODVAE_WGRAD_WINOGRAD=0 keeps the direct weight-gradient kernel everywhere
+WGRAD_WINOGRAD = os.environ.get("ODVAE_WGRAD_WINOGRAD", "1") != "0"
 
 
 def _wino_ok(h, w, cin, cout):
@@ -248,11 +251,18 @@ class _Conv3x3(Function):
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             wmode = 5 if ctx.up is True else mode
-            need = L.odvae_conv3x3_wgrad_workspace_bytes(wmode, n, ho, wo, cin, cout)
-            wp, wn = _ws(need, x)
-            _lib.check(L.odvae_conv3x3_wgrad_f32(wmode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,
-                                                 dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
-                       "conv3x3_wgrad(mode=%d)" % wmode)
+            if mode == 0 and WGRAD_WINOGRAD and L.odvae_conv3x3_wgrad_wino_supported(n, hi, wi, cin, cout):
+                need = L.odvae_conv3x3_wgrad_wino_workspace_bytes(n, hi, wi, cin, cout)
+                wp, wn = _ws(need, x)
+                _lib.check(L.odvae_conv3x3_wgrad_wino_f32(x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, cout,
+                                                          dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
+                           "conv3x3_wgrad_wino")
+            else:
+                need = L.odvae_conv3x3_wgrad_workspace_bytes(wmode, n, ho, wo, cin, cout)
+                wp, wn = _ws(need, x)
+                _lib.check(L.odvae_conv3x3_wgrad_f32(wmode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,
+                                                     dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
+                           "conv3x3_wgrad(mode=%d)" % wmode)
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None
 

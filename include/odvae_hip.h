@@ -92,6 +92,17 @@ int odvae_conv3x3_wgrad_f32(int mode, const float* x, const float* dy, int N, in
                             int Ho, int Wo, int Cout, float* dw, float* dbias,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- conv3x3_wgrad_wino_f32.hip: the same weight/bias gradient for mode 0 (stride 1, pad 1) in the Winograd
+ * F(2x2,3x3) domain: dU[xi] = sum over 2x2 tiles of (B^T d B)[xi]^T (A dY A^T)[xi], dw = G^T dU G -- 16 instead of 36
+ * multiply-adds per tile.  Serves even H, W, channel counts in multiples of 128 and tensors below 4 GiB
+ * (..._supported() == 1); everything else stays on odvae_conv3x3_wgrad_f32.  dw OIHW overwritten; dbias [Cout] or NULL.
+ * Replaces autograd's weight gradient of F.conv2d(x, w, b, stride=1, padding=1) ([UPSTREAM] ldm ResnetBlock.conv1/conv2,
+ * Encoder/Decoder convs; reference call sites src/modules/autoencodermodules/feat_encoder.py:2, feat_decoder.py:2). */
+int odvae_conv3x3_wgrad_wino_supported(int N, int H, int W, int Cin, int Cout);
+size_t odvae_conv3x3_wgrad_wino_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int odvae_conv3x3_wgrad_wino_f32(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout,
+                                 float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- groupnorm.hip: Normalize = GroupNorm(32, C, eps=1e-6) followed by x*sigmoid(x) -----------------
  * x,y: [N][HW][C]; mean,rstd: [N][G]; swish: 0 identity, 1 x*sigmoid(x). */
 size_t odvae_groupnorm_workspace_bytes(int N, int HW, int C, int G);

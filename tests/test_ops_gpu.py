@@ -137,6 +137,7 @@ def test_conv3x3_direct_kernel_still_matches(hip_lib, monkeypatch, case):
     that Winograd serves by default."""
     from odvae_amd import ops
     monkeypatch.setattr(ops, "WINOGRAD", False)
+    monkeypatch.setattr(ops, "WGRAD_WINOGRAD", False)   # and the direct weight-gradient kernel on the 256 -> 256 case
     test_conv3x3_fwd_bwd(hip_lib, *case)
 
 
@@ -156,6 +157,42 @@ def test_winograd_and_direct_kernels_agree(hip_lib, monkeypatch):
         outs.append((y.detach(), xd.grad))
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 128, 16, 16), (1, 128, 256, 8, 12), (3, 256, 128, 6, 10),
+                                            (2, 128, 128, 2, 2), (1, 384, 128, 4, 34)])
+def test_winograd_domain_weight_gradient(hip_lib, n, cin, cout, h, w):
+    """odvae_conv3x3_wgrad_wino_f32 through the C ABI against torch CPU (weight and bias gradient) and against the direct
+    weight-gradient kernel: ragged last chunk (tiles not a multiple of 16), tiles of one chunk in different images, a
+    single tile row, three channel blocks."""
+    from odvae_amd import lib as _lib, ops
+    L = hip_lib
+    g = torch.Generator().manual_seed(n * 1000 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    F.conv2d(x, wt, b, padding=1).backward(dy)
+    xd = x.to(dev()).permute(0, 2, 3, 1).contiguous()
+    dyd = dy.to(dev()).permute(0, 2, 3, 1).contiguous()
+    assert L.odvae_conv3x3_wgrad_wino_supported(n, h, w, cin, cout) == 1
+    dw = torch.empty(cout, cin, 3, 3, device=dev()); db = torch.empty(cout, device=dev())
+    wp, wn = ops._ws(L.odvae_conv3x3_wgrad_wino_workspace_bytes(n, h, w, cin, cout), xd)
+    _lib.check(L.odvae_conv3x3_wgrad_wino_f32(xd.data_ptr(), dyd.data_ptr(), n, h, w, cin, cout, dw.data_ptr(), db.data_ptr(),
+                                              wp, wn, _lib.stream_ptr()), "wgrad_wino")
+    dw2 = torch.empty_like(dw); db2 = torch.empty_like(db)
+    wp, wn = ops._ws(L.odvae_conv3x3_wgrad_workspace_bytes(0, n, h, w, cin, cout), xd)
+    _lib.check(L.odvae_conv3x3_wgrad_f32(0, xd.data_ptr(), dyd.data_ptr(), n, h, w, cin, h, w, cout, dw2.data_ptr(), db2.data_ptr(),
+                                         wp, wn, _lib.stream_ptr()), "wgrad")
+    close(dw, wt.grad, BWD_TOL, "winograd-domain dw vs torch")
+    close(db, b.grad, BWD_TOL, "winograd-domain dbias vs torch")
+    close(dw, dw2.cpu(), 1e-5, "winograd-domain dw vs direct kernel")
+    # unsupported shapes are refused, not mis-served
+    assert L.odvae_conv3x3_wgrad_wino_supported(n, h + 1, w, cin, cout) == 0
+    assert L.odvae_conv3x3_wgrad_wino_supported(n, h, w, cin + 4, cout) == 0
+    rc = L.odvae_conv3x3_wgrad_wino_f32(xd.data_ptr(), dyd.data_ptr(), n, h, w, cin + 4, cout, dw.data_ptr(), db.data_ptr(),
+                                        wp, wn, _lib.stream_ptr())
+    assert rc != 0
 
 
 def test_upsample_conv_dense_form_still_matches(hip_lib, monkeypatch):
