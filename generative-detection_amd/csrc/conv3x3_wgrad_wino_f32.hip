@@ -42,13 +42,19 @@ __device__ __forceinline__ float4 f4lin(float a, float4 x, float b, float4 y) {
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+template <bool WIDE>   // WIDE: a tile row holds at least CT tiles, the per-chunk tile advance needs no division
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];   // stage s: V at s*2*OPF, dM at s*2*OPF + OPF
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cig = wave & 3, coh = wave >> 2;
   const int li = lane & 31, h = lane >> 5;
-  const int r = blockIdx.x & 3, split = blockIdx.x >> 2;
+  // the four row blocks of one tile split read the same x / dy: linear block ids go round-robin over the 8 XCDs, so
+  // ids bx, bx + 8, bx + 16, bx + 24 (one XCD, one L2) take the four rows of one split when the split count allows it
+  const int bx = blockIdx.x;
+  const bool xcd_map = (p.nsplit & 7) == 0;
+  const int r = xcd_map ? (bx >> 3) & 3 : bx & 3;
+  const int split = xcd_map ? (bx & 7) + 8 * (bx >> 5) : bx >> 2;
   const int cib = blockIdx.y, cob = blockIdx.z;
   // row r of B^T d = sa * d[ra] + sb * d[rb];  row r of A dY = ya * dy[0] + yb * dy[1]
   const int ra = r == 0 ? 0 : 1, rb = r == 3 ? 3 : 2;
@@ -60,37 +66,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.dy), 0, (unsigned)((int64_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
 
+  const int chunk0 = split * p.chunks_per_split;
+  const int nch = min(p.chunks_per_split, p.total_chunks - chunk0);   // >= 1 by construction of nsplit
+  const int end_tile = min(p.total_tiles, (chunk0 + nch) * CT);         // fetches past it return zeros (no traffic)
+
   const int st = tid >> 5, sq = tid & 31;     // staging role: tile of the chunk, channel quad
-  float4 xr[2][4], yr[2][2];
-  auto fetch = [&](int chunk) {
-    const int tl = chunk * CT + st;
-    const bool valid = tl < p.total_tiles;
+  // this thread's tile of the next chunk to fetch, advanced by CT per fetch (one division at the start only when a
+  // tile row holds at least CT tiles); all byte offsets fit 32 bits (tensors below 4 GiB, checked by the launcher)
+  int tl = chunk0 * CT + st, tn, tty, ttx;
+  {
     const int per_img = p.TY * p.TX;
-    const int n = tl / per_img, rem = tl - n * per_img;
-    const int ty = rem / p.TX, tx = rem - ty * p.TX;
+    tn = tl / per_img;
+    const int rem = tl - tn * per_img;
+    tty = rem / p.TX; ttx = rem - tty * p.TX;
+  }
+  const unsigned cin4 = (unsigned)p.Cin * 4u, cout4 = (unsigned)p.Cout * 4u;
+  const unsigned chx = (unsigned)(cib * 128 + 4 * sq) * 4u, chy = (unsigned)(cob * 128 + 4 * sq) * 4u;
+  float4 xr[2][4], yr[2][2];
+  auto fetch_x = [&]() {
+    const bool valid = tl < end_tile;
+    const int prow = tn * p.H + 2 * tty - 1;                     // input row of patch row 0 (may be -1: masked below)
+    const bool rok0 = valid && (ra != 0 || tty > 0), rok1 = valid && (rb != 3 || tty < p.TY - 1);
+    const bool cok0 = ttx > 0, cok3 = ttx < p.TX - 1;
+    const unsigned xo0 = (unsigned)((prow + ra) * p.W + 2 * ttx - 1) * cin4 + chx;
+    const unsigned xo1 = (unsigned)((prow + rb) * p.W + 2 * ttx - 1) * cin4 + chx;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int iy = 2 * ty - 1 + (rr ? rb : ra);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ix = 2 * tx - 1 + c;
-        const bool ok = valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        const unsigned off = ok ? (unsigned)((((int64_t)(n * p.H + iy) * p.W + ix) * p.Cin + cib * 128 + 4 * sq) * 4) : OOB;
-        xr[rr][c] = f4(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0));
-      }
+    for (int c = 0; c < 4; ++c) {
+      const bool cok = c == 0 ? cok0 : (c == 3 ? cok3 : true);
+      xr[0][c] = f4(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, (rok0 && cok) ? xo0 + c * cin4 : OOB, 0, 0));
+      xr[1][c] = f4(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, (rok1 && cok) ? xo1 + c * cin4 : OOB, 0, 0));
     }
+  };
+  auto fetch_y = [&]() {     // and advance to this thread's tile of the following chunk
+    const bool valid = tl < end_tile;
+    const unsigned yo0 = (unsigned)((tn * p.H + 2 * tty) * p.W + 2 * ttx) * cout4 + chy;
+    const unsigned yo1 = yo0 + (unsigned)p.W * cout4;
+    const bool u0 = valid && ya != 0.f, u1 = valid && yb != 0.f;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const bool used = valid && (rr ? yb : ya) != 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned off = used ? (unsigned)((((int64_t)(n * p.H + 2 * ty + rr) * p.W + 2 * tx + j) * p.Cout + cob * 128 + 4 * sq) * 4) : OOB;
-        yr[rr][j] = f4(__builtin_amdgcn_raw_buffer_load_b128(yrsrc, off, 0, 0));
-      }
+    for (int j = 0; j < 2; ++j) {
+      yr[0][j] = f4(__builtin_amdgcn_raw_buffer_load_b128(yrsrc, u0 ? yo0 + j * cout4 : OOB, 0, 0));
+      yr[1][j] = f4(__builtin_amdgcn_raw_buffer_load_b128(yrsrc, u1 ? yo1 + j * cout4 : OOB, 0, 0));
+    }
+    tl += CT;
+    if constexpr (WIDE) {
+      ttx += CT;
+      if (ttx >= p.TX) { ttx -= p.TX; tty += 1; if (tty >= p.TY) { tty = 0; tn += 1; } }
+    } else {
+      const int per_img = p.TY * p.TX;
+      tn = tl / per_img;
+      const int rem = tl - tn * per_img;
+      tty = rem / p.TX; ttx = rem - tty * p.TX;
     }
   };
   float4 bias_acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto stage = [&](float* V, float* M) {
+  auto stage_x = [&](float* V) {
     float4 w[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) w[c] = f4lin(sa, xr[0][c], sb, xr[1][c]);
@@ -99,6 +128,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
     *reinterpret_cast<float4*>(vd + 1 * CT * RS) = f4add(w[1], w[2]);
     *reinterpret_cast<float4*>(vd + 2 * CT * RS) = f4sub(w[2], w[1]);
     *reinterpret_cast<float4*>(vd + 3 * CT * RS) = f4sub(w[1], w[3]);
+  };
+  auto stage_y = [&](float* M) {
     const float4 z0 = f4lin(ya, yr[0][0], yb, yr[1][0]), z1 = f4lin(ya, yr[0][1], yb, yr[1][1]);
     const float4 m1 = f4add(z0, z1);
     float* md = M + st * RS + 4 * sq;
@@ -117,38 +148,65 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[c][nt][q] = 0.f;
 
-  auto mma = [&](const float* V, const float* M) {
-    const float* va = V + h * RS + cig * 32 + li;
-    const float* mb = M + h * RS + coh * 64 + li;
+  // fragments of k step t2 (tiles 2 t2, 2 t2 + 1) into set s; eight MFMAs per step
+  float fa[2][4], fb[2][4][2];
+  auto ldf = [&](const float* va, const float* mb, int t2, int s) {
 #pragma unroll
-    for (int t2 = 0; t2 < CT / 2; ++t2) {
-      float a[4], b[4][2];
+    for (int c = 0; c < 4; ++c) {
+      fa[s][c] = va[(c * CT + 2 * t2) * RS];
+      fb[s][c][0] = mb[(c * CT + 2 * t2) * RS];
+      fb[s][c][1] = mb[(c * CT + 2 * t2) * RS + 32];
+    }
+  };
+  auto mm = [&](int s) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        a[c] = va[(c * CT + 2 * t2) * RS];
-        b[c][0] = mb[(c * CT + 2 * t2) * RS];
-        b[c][1] = mb[(c * CT + 2 * t2) * RS + 32];
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[c][0] = mfma32(a[c], b[c][0], acc[c][0]);
-        acc[c][1] = mfma32(a[c], b[c][1], acc[c][1]);
-      }
+    for (int c = 0; c < 4; ++c) {
+      acc[c][0] = mfma32(fa[s][c], fb[s][c][0], acc[c][0]);
+      acc[c][1] = mfma32(fa[s][c], fb[s][c][1], acc[c][1]);
     }
   };
 
-  const int chunk0 = split * p.chunks_per_split;
-  const int nch = min(p.chunks_per_split, p.total_chunks - chunk0);   // >= 1 by construction of nsplit
-  fetch(chunk0);
-  stage(dsm, dsm + OPF);
-  if (nch > 1) fetch(chunk0 + 1);
+  // One basic block per iteration, pieces pinned in this order (fragments of step t+1 are requested before the MFMAs of
+  // step t; staging of chunk k+1 and the fetch of chunk k+2 ride under the MFMAs of steps 0-3; past the end of the split
+  // both move zeros):  [f1] [mm0 | V writes] [f2] [mm1 | dM writes] [f3] [mm2 | x fetch] [f4] [mm3 | dy fetch] ...
+  fetch_x(); fetch_y();
+  stage_x(dsm); stage_y(dsm + OPF);
+  fetch_x(); fetch_y();
   __syncthreads();
   for (int k = 0; k < nch; ++k) {
-    float* cur = dsm + (k & 1) * 2 * OPF;
+    const float* cur = dsm + (k & 1) * 2 * OPF;
     float* nxt = dsm + ((k + 1) & 1) * 2 * OPF;
-    if (k + 1 < nch) stage(nxt, nxt + OPF);
-    if (k + 2 < nch) fetch(chunk0 + k + 2);
-    mma(cur, cur + OPF);
+    const float* va = cur + h * RS + cig * 32 + li;
+    const float* mb = cur + OPF + h * RS + coh * 64 + li;
+    ldf(va, mb, 0, 0);
+    ldf(va, mb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0); stage_x(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(va, mb, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(1); stage_y(nxt + OPF);
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(va, mb, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0); fetch_x();
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(va, mb, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(1); fetch_y();
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(va, mb, 5, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(va, mb, 6, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(1);
+    __builtin_amdgcn_sched_barrier(0);
+    ldf(va, mb, 7, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0);
+    mm(1);
     __syncthreads();
   }
 
@@ -253,14 +311,14 @@ int odvae_conv3x3_wgrad_wino_f32(const float* x, const float* dy, int N, int H, 
   p.slabs = static_cast<float*>(workspace);
   p.bias_part = dbias ? p.slabs + (size_t)p.nsplit * 16 * Cin * Cout : nullptr;
   const size_t smem = (size_t)4 * OPF * sizeof(float);
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_wino_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  auto kern = p.TX >= CT ? conv3x3_wgrad_wino_kernel<true> : conv3x3_wgrad_wino_kernel<false>;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) {
     odvae_set_error("conv3x3_wgrad_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     return ODVAE_ERR_HIP;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(4 * p.nsplit, Cin / 128, Cout / 128), dim3(512), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(4 * p.nsplit, Cin / 128, Cout / 128), dim3(512), smem, s, p);
   ODVAE_LAUNCH_CHECK("conv3x3_wgrad_wino");
   const int pairs = Cin * Cout;
   hipLaunchKernelGGL(conv3x3_wgrad_wino_reduce_kernel, dim3(ceil_div(pairs, 256)), dim3(256), 0, s,
