@@ -84,7 +84,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
   const unsigned chx = (unsigned)(cib * 128 + 4 * sq) * 4u, chy = (unsigned)(cob * 128 + 4 * sq) * 4u;
   float4 xr[2][4], yr[2][2];
   auto fetch_x = [&]() {
+#ifdef ODVAE_WGW_NOFETCH   // ablation build: every fetch is answered with zeros by the descriptor, no memory traffic
+    const bool valid = false;
+#else
     const bool valid = tl < end_tile;
+#endif
     const int prow = tn * p.H + 2 * tty - 1;                     // input row of patch row 0 (may be -1: masked below)
     const bool rok0 = valid && (ra != 0 || tty > 0), rok1 = valid && (rb != 3 || tty < p.TY - 1);
     const bool cok0 = ttx > 0, cok3 = ttx < p.TX - 1;
@@ -98,7 +102,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
     }
   };
   auto fetch_y = [&]() {     // and advance to this thread's tile of the following chunk
+#ifdef ODVAE_WGW_NOFETCH   // ablation build: every fetch is answered with zeros by the descriptor, no memory traffic
+    const bool valid = false;
+#else
     const bool valid = tl < end_tile;
+#endif
     const unsigned yo0 = (unsigned)((tn * p.H + 2 * tty) * p.W + 2 * ttx) * cout4 + chy;
     const unsigned yo1 = yo0 + (unsigned)p.W * cout4;
     const bool u0 = valid && ya != 0.f, u1 = valid && yb != 0.f;
