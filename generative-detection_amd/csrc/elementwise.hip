@@ -473,6 +473,31 @@ int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, flo
   return ODVAE_OK;
 }
 
+// out[row] = sum_c a[row][c] * b[row][c]: one wavefront per row, float4 lanes (attention backward: dO[i] . O[i])
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     int64_t rows, int cols, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const float4* pa = reinterpret_cast<const float4*>(a + row * cols);
+    const float4* pb = reinterpret_cast<const float4*>(b + row * cols);
+    float s = 0.f;
+    for (int q = lane; q < cols / 4; q += 64) {
+      const float4 x = pa[q], y = pb[q];
+      s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+  }
+}
+
+int odvae_rowdot_f32(const float* a, const float* b, int64_t rows, int cols, float* out, void* stream) {
+  ODVAE_CHECK_ARG(a && b && out && rows > 0 && cols > 0 && cols % 4 == 0, "rowdot: need cols %% 4 == 0");
+  const dim3 grid((unsigned)std::min<int64_t>(ceil_div64(rows, 4), 65536)), block(256);
+  hipLaunchKernelGGL(rowdot_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a, b, rows, cols, out);
+  ODVAE_LAUNCH_CHECK("rowdot");
+  return ODVAE_OK;
+}
+
 int odvae_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, void* stream) {
   ODVAE_CHECK_ARG(p && dp && ds && rows > 0 && cols > 0 && cols % 4 == 0, "softmax_rows_bwd: need cols %% 4 == 0");
   const dim3 grid((unsigned)std::min<int64_t>(rows, 65536 * 4)), block(256);

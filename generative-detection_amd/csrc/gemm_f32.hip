@@ -36,6 +36,8 @@ struct GemmParams {
   float alpha;
   int splits, k_per_split;
   int tiles_m;
+  // softmax-backward epilogue (SMB kernels only): C = alpha * emul .* (A B^T - rowsub[row]); emul has C's layout
+  const float* rowsub; const float* emul; int64_t sRow;
 };
 
 template <bool KC>
@@ -80,7 +82,7 @@ __device__ __forceinline__ void read_frag(const float* S, int row, int g, int h,
   }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool SMB = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
   float* As = smem;
@@ -121,7 +123,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   };
 
   f32x16 acc[2][2];
-  if (!to_partial && p.residual) {
+  if constexpr (SMB) {   // accumulators start at -rowsub[row]: the products then add up to dP - D
+    const float* rs = p.rowsub + batch * p.sRow + m0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mt * 32 + acc_row(r, lane);
+        const float d = row < rows_here ? -rs[row] : 0.f;
+        acc[mt][0][r] = d; acc[mt][1][r] = d;
+      }
+  } else if (!to_partial && p.residual) {
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.residual) + batch * p.sC + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
 #pragma unroll
@@ -187,6 +199,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   for (int nt = 0; nt < 2; ++nt)
     bv[nt] = (!to_partial && p.bias) ? p.bias[min(n0 + wn * 64 + nt * 32 + li, p.N - 1)] : 0.f;
   const float alpha = to_partial ? 1.f : p.alpha;
+  if constexpr (SMB) {   // all loads of the multiplier tile first, then stores only
+    const __amdgpu_buffer_rsrc_t ersrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.emul) + batch * p.sC + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
+    float pv[2][2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rb_ = row_byte(mt, r);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          pv[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ersrc, rb_ + colbyte[nt], 0, 0));
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rb_ = row_byte(mt, r);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * alpha * pv[mt][nt][r]), crsrc, rb_ + colbyte[nt], 0, 0);
+      }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -261,6 +297,7 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.partial = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
+  p.rowsub = nullptr; p.emul = nullptr; p.sRow = 0;
   p.splits = choose_splits(M, N, K, batch);
   p.k_per_split = ceil_div(ceil_div(K, p.splits), BK) * BK;
   p.tiles_m = ceil_div(M, BM);
@@ -286,6 +323,36 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, batch);
     ODVAE_LAUNCH_CHECK("gemm_f32 split-K reduce");
   }
+  return ODVAE_OK;
+}
+
+// Attention backward, the product dP = dO V^T with the softmax backward folded into its epilogue:
+//   dS = alpha * P .* (A B^T - rowdot[row]),   rowdot[i] = sum_j P[i][j] dP[i][j] = dO[i] . O[i]
+// (the row sum of P .* dP equals the dot product of the output row and its gradient, so it is known before dP is).
+// A [M][K], B [N][K] (both k-contiguous), P and dS [M][N] with leading dimension ldc and batch stride strideC (dS may
+// alias P), rowdot [batch][M] with batch stride strideRow.  Replaces bmm + the softmax backward of
+// [UPSTREAM] ldm AttnBlock.forward under autograd.
+int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha,
+                               const float* A, int lda, int64_t strideA,
+                               const float* B, int ldb, int64_t strideB,
+                               const float* P, const float* rowdot, int64_t strideRow,
+                               float* dS, int ldc, int64_t strideC, int batch, void* stream) {
+  ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_softmax_bwd: empty shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  ODVAE_CHECK_ARG(A && B && P && rowdot && dS, "gemm_softmax_bwd: null operand");
+  ODVAE_CHECK_ARG(batch <= 65535, "gemm_softmax_bwd: batch %d > 65535", batch);
+  ODVAE_CHECK_ARG((int64_t)BM * ldc * 4 < 0x7FFFFFF0ll, "gemm_softmax_bwd: ldc %d too large for 32-bit tile offsets", ldc);
+  ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 && K % 4 == 0,
+                  "gemm_softmax_bwd: lda/ldb/strides/K must be multiples of 4 floats");
+  ODVAE_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_softmax_bwd: A/B must be 16-byte aligned");
+  GemmParams p;
+  p.A = A; p.B = B; p.C = dS; p.bias = nullptr; p.residual = nullptr; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
+  p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
+  p.rowsub = rowdot; p.emul = P; p.sRow = strideRow;
+  dim3 grid(p.tiles_m * ceil_div(N, BN), 1, batch), block(256);
+  hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), grid, block, 0, static_cast<hipStream_t>(stream), p);
+  ODVAE_LAUNCH_CHECK("gemm_softmax_bwd");
   return ODVAE_OK;
 }
 

@@ -338,6 +338,10 @@ def conv1x1(x, weight, bias=None, residual=None):
     return _Conv1x1.apply(x, weight, bias, residual)
 
 
+# softmax backward folded into the dP product's epilogue; ODVAE_ATTN_UNFUSED=1 keeps the separate row-wise pass
+FUSED_SOFTMAX_BWD = os.environ.get("ODVAE_ATTN_UNFUSED", "0") != "1"
+
+
 class _Attention(Function):
     """Single-head attention over T = H*W tokens from a packed qkv tensor [N, 3C, H, W]:
     softmax(q k^T * C^-0.5) v  ([UPSTREAM] AttnBlock.forward).  Scores live in HBM (T x T per image)."""
@@ -359,13 +363,13 @@ class _Attention(Function):
         gemm(0, 1, t, t, c, 1.0, q, c3, sq, k, c3, sq, p, t, t * t, batch=n)
         _lib.check(L.odvae_softmax_rows_f32(p.data_ptr(), p.data_ptr(), n * t, t, scale, _lib.stream_ptr()), "softmax_rows")
         gemm(0, 0, t, c, t, 1.0, p, t, t * t, v, c3, sq, o, c, t * c, batch=n)
-        ctx.save_for_backward(qkv, p)
+        ctx.save_for_backward(qkv, p, o)
         return o
 
     @staticmethod
     def backward(ctx, do):
         L = _L()
-        qkv, p = ctx.saved_tensors
+        qkv, p, o = ctx.saved_tensors
         do = _cl(do)
         n, c3, h, w = qkv.shape
         c = c3 // 3
@@ -381,11 +385,19 @@ class _Attention(Function):
         dv = dqkv.as_strided((1,), (1,), dqkv.storage_offset() + 2 * c)
         # dV = P^T dO
         gemm(1, 0, t, c, t, 1.0, p, t, t * t, do, c, t * c, dv, c3, sq, batch=n)
-        # dP = dO V^T, then dS in place
+        # dS = scale * P .* (dO V^T - D), D[i] = sum_j P[i][j] dP[i][j] = dO[i] . O[i]: the softmax backward rides in the
+        # epilogue of the dP product (no dP round trip through HBM, no separate softmax-backward pass)
         dp = torch.empty_like(p)
-        gemm(0, 1, t, t, c, 1.0, do, c, t * c, v, c3, sq, dp, t, t * t, batch=n)
-        _lib.check(L.odvae_softmax_rows_bwd_f32(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), n * t, t, scale,
-                                                _lib.stream_ptr()), "softmax_rows_bwd")
+        if FUSED_SOFTMAX_BWD:
+            drow = torch.empty(n * t, dtype=torch.float32, device=p.device)
+            _lib.check(L.odvae_rowdot_f32(do.data_ptr(), o.data_ptr(), n * t, c, drow.data_ptr(), _lib.stream_ptr()), "rowdot")
+            _lib.check(L.odvae_gemm_softmax_bwd_f32(t, t, c, scale, do.data_ptr(), c, t * c, v.data_ptr(), c3, sq, p.data_ptr(),
+                                                    drow.data_ptr(), t, dp.data_ptr(), t, t * t, n, _lib.stream_ptr()),
+                       "gemm_softmax_bwd")
+        else:
+            gemm(0, 1, t, t, c, 1.0, do, c, t * c, v, c3, sq, dp, t, t * t, batch=n)
+            _lib.check(L.odvae_softmax_rows_bwd_f32(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), n * t, t, scale,
+                                                    _lib.stream_ptr()), "softmax_rows_bwd")
         # dQ = dS K ; dK = dS^T Q
         gemm(0, 0, t, c, t, 1.0, dp, t, t * t, k, c3, sq, dq, c3, sq, batch=n)
         gemm(1, 0, t, c, t, 1.0, dp, t, t * t, q, c3, sq, dk, c3, sq, batch=n)

@@ -120,6 +120,13 @@ int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int 
 /* torch.nn.functional.softmax(scale * x, dim=-1) over rows (AttnBlock); y may alias x */
 int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, float scale, void* stream);
 int odvae_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, void* stream);
+/* Attention backward with the softmax backward folded into the product dP = dO V^T ([UPSTREAM] ldm AttnBlock.forward under
+ * autograd): rowdot[i] = dO[i] . O[i] (= sum_j P[i][j] dP[i][j]); dS = alpha * P .* (A B^T - rowdot[row]).
+ * A [M][K], B [N][K]; P, dS [M][N] (leading dimension ldc, batch stride strideC; dS may alias P); rowdot [batch][M]. */
+int odvae_rowdot_f32(const float* a, const float* b, int64_t rows, int cols, float* out, void* stream);
+int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA,
+                               const float* B, int ldb, int64_t strideB, const float* P, const float* rowdot,
+                               int64_t strideRow, float* dS, int ldc, int64_t strideC, int batch, void* stream);
 /* backward of F.interpolate(scale_factor=2, mode="nearest"): dx[N][H][W][C] from du[N][2H][2W][C] */
 int odvae_upsample2x_bwd_f32(const float* du, float* dx, int N, int H, int W, int C, void* stream);
 /* PoseAutoencoder._rescale (src/models/autoencoder.py:434-436): NCHW in, NHWC out; workspace >= 8 KiB */

@@ -282,9 +282,13 @@ def test_conv1x1(hip_lib, n, cin, cout, h, w):
     close(rd.grad, rr.grad, 1e-6, "1x1 dres")
 
 
-@pytest.mark.parametrize("n,c,h,w", [(2, 32, 4, 4), (2, 64, 16, 16), (1, 256, 8, 16)])
-def test_attention(hip_lib, n, c, h, w):
+@pytest.mark.parametrize("fused", [True, False], ids=["softmax-bwd-in-gemm", "softmax-bwd-separate"])
+@pytest.mark.parametrize("n,c,h,w", [(2, 32, 4, 4), (2, 64, 16, 16), (1, 256, 8, 16), (2, 64, 10, 18)])
+def test_attention(hip_lib, monkeypatch, n, c, h, w, fused):
+    """fused: the softmax backward rides in the epilogue of the dP product (odvae_gemm_softmax_bwd_f32 + odvae_rowdot_f32);
+    separate: bmm, then odvae_softmax_rows_bwd_f32.  (10 x 18 = 180 tokens: ragged 128-wide tiles on both axes.)"""
     from odvae_amd import ops
+    monkeypatch.setattr(ops, "FUSED_SOFTMAX_BWD", fused)
     g = torch.Generator().manual_seed(c + h * w)
     qkv = torch.randn(n, 3 * c, h, w, generator=g)
     qr = qkv.clone().requires_grad_(True)
