@@ -50,6 +50,7 @@ class _KernelEvents:
 
     def __init__(self):
         self.on = False
+        self.extra = False    # also bracket the secondary kernel families (bench.py: one extra step after the timed region)
         self.rec = {}
 
     def enable(self):
@@ -58,8 +59,8 @@ class _KernelEvents:
     def disable(self):
         self.on = False
 
-    def begin(self):
-        if not self.on:
+    def begin(self, secondary=False):
+        if not self.on or (secondary and not self.extra):
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
@@ -254,9 +255,12 @@ class _Conv3x3(Function):
             if mode == 0 and WGRAD_WINOGRAD and L.odvae_conv3x3_wgrad_wino_supported(n, hi, wi, cin, cout):
                 need = L.odvae_conv3x3_wgrad_wino_workspace_bytes(n, hi, wi, cin, cout)
                 wp, wn = _ws(need, x)
+                tag = KERNEL_EVENTS.begin(secondary=True)
                 _lib.check(L.odvae_conv3x3_wgrad_wino_f32(x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, cout,
                                                           dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
                            "conv3x3_wgrad_wino")
+                KERNEL_EVENTS.end("conv3x3_wgrad_wino", 2.0 * 9 * cin * cout * n * hi * wi, tag,
+                                  4.0 * (n * hi * wi * (cin + cout) + 9 * cin * cout))
             else:
                 need = L.odvae_conv3x3_wgrad_workspace_bytes(wmode, n, ho, wo, cin, cout)
                 wp, wn = _ws(need, x)
@@ -279,9 +283,11 @@ def gemm(ta, tb, m, n, k, alpha, a, lda, sa, b, ldb, sb, c, ldc, sc, bias=None, 
     L = _L()
     need = L.odvae_gemm_f32_workspace_bytes(m, n, k, batch)
     wp, wn = _ws(need, c) if need else (None, 0)
+    tag = KERNEL_EVENTS.begin(secondary=True)
     _lib.check(L.odvae_gemm_f32(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), lda, sa, b.data_ptr(), ldb, sb,
                                 c.data_ptr(), ldc, sc, _lib.ptr(bias), _lib.ptr(residual), batch, wp, wn,
                                 _lib.stream_ptr()), "gemm_f32")
+    KERNEL_EVENTS.end("gemm_f32", 2.0 * m * n * k * batch, tag, 4.0 * batch * (m * k + k * n + m * n))
 
 
 def _colsum(x2d_ptr_tensor, rows, c):
@@ -391,9 +397,11 @@ class _Attention(Function):
         if FUSED_SOFTMAX_BWD:
             drow = torch.empty(n * t, dtype=torch.float32, device=p.device)
             _lib.check(L.odvae_rowdot_f32(do.data_ptr(), o.data_ptr(), n * t, c, drow.data_ptr(), _lib.stream_ptr()), "rowdot")
+            tag = KERNEL_EVENTS.begin(secondary=True)
             _lib.check(L.odvae_gemm_softmax_bwd_f32(t, t, c, scale, do.data_ptr(), c, t * c, v.data_ptr(), c3, sq, p.data_ptr(),
                                                     drow.data_ptr(), t, dp.data_ptr(), t, t * t, n, _lib.stream_ptr()),
                        "gemm_softmax_bwd")
+            KERNEL_EVENTS.end("gemm_f32", 2.0 * t * t * c * n, tag, 4.0 * n * (2 * t * c + 2 * t * t))
         else:
             gemm(0, 1, t, t, c, 1.0, do, c, t * c, v, c3, sq, dp, t, t * t, batch=n)
             _lib.check(L.odvae_softmax_rows_bwd_f32(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), n * t, t, scale,
