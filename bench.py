@@ -214,7 +214,7 @@ def main():
                 out["roofline_others"].append(e)
         print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.res)
+            out["cpu_baseline"] = cpu_baseline(args.res, batch=2, steps=2)   # about 10 s of host work on 16 cores
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
