@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from odvae_amd import lib as _lib, ops
 
 dev = "cuda:0"
+if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/bin/, not shipped)
+    _lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
 L = _lib.load()
 
 
