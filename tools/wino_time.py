@@ -1,7 +1,9 @@
 """Time the default 3x3 conv forward on two layer shapes (used for rocprofv3 --pmc passes and ablation builds)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from odvae_amd import ops
+from odvae_amd import ops, lib as _lib
+if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/bin/, not shipped)
+    _lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
 dev = "cuda:0"
 for (b, cin, cout, h) in [(32,128,128,256),(32,256,256,64)]:
     x = torch.randn(b, h, h, cin, device=dev).permute(0,3,1,2)
