@@ -23,21 +23,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 YAML = os.path.join(ROOT, "tests", "golden", "autoencoder_kl_16x16x16.yaml")
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16, dense
+PEAK_HBM_GBS = 8000.0          # HBM3E
+ALGORITHMIC_GFLOP_PER_IMAGE = {256: 1449.9, 512: 8901.6, 64: 75.5}   # fwd + bwd, VAE only
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)     # >= 50 timed steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--gan", action="store_true",
                     help="BASELINE.json configs[3]: PatchGAN discriminator + LPIPS-style loss, both optimizers per batch")
+    ap.add_argument("--bf16", action="store_true",
+                    help="BASELINE.json configs[4]: bf16 mixed precision (bf16 activations in HBM, fp32 master weights and accumulation)")
     ap.add_argument("--ckpt-decoder", action="store_true",
                     help="BASELINE.json configs[4]: activation-checkpointed Decoder (each up level / mid block is recomputed in backward)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL with world size 1 and run the bucketed reducer anyway")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU rehearsal of the N-rank launch path: ranks rendezvous over gloo, count themselves and run the "
+                         "bucketed reducer on host tensors; no HIP kernel runs and the printed line is marked as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
@@ -84,13 +92,90 @@ def cpu_baseline(res, batch=1, steps=1):
             "sample": "%d step(s), B=%d, %dx%d, fp32, rec+KL only, torch %s CPU oracle" % (steps, batch, res, res, torch.__version__)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: this process touches no GPU (no HIP call, no
+    torch.cuda.*: a process that has initialised the device must not spawn-by-exec on this pool) and starts N fresh ranks
+    with torch.distributed.run, one per GPU, over RCCL (the reference: `strategy: ddp`, yaml:137, train.py:162).  Rank 0's
+    one JSON line is forwarded on stdout; the exit code is non-zero unless exactly N ranks joined."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings need it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in proc.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write("[bench] %d-rank launch failed (rc %d, %d JSON lines)\n" % (args.gpus, proc.returncode, len(lines)))
+        return proc.returncode or 1
+    out = json.loads(lines[-1])
+    if out.get("n_gpus") != args.gpus or out.get("ranks_joined") != args.gpus:
+        sys.stderr.write("[bench] asked for %d ranks, result reports n_gpus=%r ranks_joined=%r\n"
+                         % (args.gpus, out.get("n_gpus"), out.get("ranks_joined")))
+        return 3
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def launcher_selftest(args, json_fd):
+    """The N-rank plumbing without a GPU (tests/test_bench_launcher.py): env rendezvous, rank count by all-reduce, the
+    bucketed GradReducer on host tensors, max-over-ranks timing, one JSON line from rank 0."""
+    import torch.distributed as dist
+    from odvae_amd.parallel import GradReducer
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    joined = torch.ones(1)
+    dist.all_reduce(joined)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 16))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    red = GradReducer(opt, bucket_mb=0.002, prescaled=True)
+    red.broadcast_parameters(net)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = torch.randn(4, 16, generator=torch.Generator().manual_seed(100 * rank + i))
+        opt.zero_grad()
+        red.prepare_for_backward()
+        (net(x).pow(2).mean() * red.inv_world).backward()
+        red.finish()
+        opt.step()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    digest = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).double().sum()
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out = {"metric": "launcher self-test (gloo, host tensors; NOT a benchmark)", "value": 4 * world * args.steps / t.item(),
+               "unit": "samples/s", "n_gpus": world, "ranks_joined": int(joined.item()), "backend": "gloo",
+               "steps": args.steps, "warmup": 0, "ranks_in_lockstep": bool(lo.item() == hi.item()), "selftest": True}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))   # before anything touches the GPU
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and not args.force_dist:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     # RCCL prints banner lines ("Hostname", "Librccl path") on fd 1; the contract is ONE JSON line on stdout, so
     # everything else that lands on fd 1 is routed to stderr and the result is written to the saved descriptor
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.launcher_selftest:
+        return launcher_selftest(args, json_fd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,6 +189,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        joined = torch.ones(1, device=dev)
+        dist.all_reduce(joined)                     # the ranks count themselves over RCCL
+        ranks_joined = int(joined.item())
+    else:
+        ranks_joined = 1
     from odvae_amd import ops, synthetic
     from odvae_amd.trainer import Trainer
 
@@ -149,6 +239,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     roof = ops.KERNEL_EVENTS.summary("conv3x3_128x128") if not args.no_kernel_events else None
+    ops.KERNEL_EVENTS.issued_timed = ops.KERNEL_EVENTS.issued
     others, extra_ms = {}, None
     if roof is not None:   # ONE more step, outside the timed region, with the secondary kernel families bracketed as well
         ops.KERNEL_EVENTS.extra = True
@@ -157,7 +248,7 @@ def main():
         step(args.warmup + args.steps)
         torch.cuda.synchronize()
         extra_ms = (time.perf_counter() - t1) * 1e3
-        others = {k: ops.KERNEL_EVENTS.summary(k) for k in ("conv3x3_wgrad_wino", "gemm_f32")}
+        others = {k: ops.KERNEL_EVENTS.summary(k) for k in ("conv3x3_wgrad_wino", "gemm_f32", "flash_attn", "groupnorm")}
     ops.KERNEL_EVENTS.disable()
 
     if rank == 0:
@@ -166,7 +257,7 @@ def main():
             "metric": "VAE train images/s (fwd+bwd+opt) at %dx%d z=%dx%dx16" % (args.res, args.res, lat, lat),
             "value": args.batch * world * args.steps / elapsed,
             "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "n_gpus": world, "ranks_joined": ranks_joined, "backend": "rccl" if use_dist else "none", "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
@@ -178,43 +269,65 @@ def main():
         }
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
-            tpath = os.path.join(ROOT, "profiles", "r01_conv3x3_traffic.json")
-            if os.path.exists(tpath) and not args.gan and args.batch == 32 and args.res == 256 and not args.ckpt_decoder:
-                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            tfile = None
+            for cand in ("r02_conv3x3_traffic.json", "r01_conv3x3_traffic.json"):
+                if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                    tfile = cand
+                    break
+            if tfile and not args.gan and args.batch == 32 and args.res == 256 and not args.ckpt_decoder and not args.bf16:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["hbm_bytes_per_launch"]
             wino = ops.WINOGRAD
-            out["roofline"] = {"bound": "mfma", "achieved": roof["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": roof["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                               "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_conv3x3_traffic.json)",
+            ratio = 16.0 / 36.0 if wino else 1.0      # Winograd F(2x2,3x3) issues 16 of the direct form's 36 multiply-adds
+            issued = roof["tflops"] * ratio
+            out["roofline"] = {"bound": "mfma", "achieved": issued, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": issued / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile,
                                "kernel": ("conv3x3_wino8_kernel (stride-1 3x3 conv fwd + dgrad, Winograd F(2x2,3x3), 32 tiles x 128 co per block)"
                                           if wino else "conv3x3_kernel_v2<MODE 0,KC 32,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)"),
                                "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
+                               "issued_gflop_per_launch": roof["gflop_per_launch"] * ratio,
                                "algorithmic_gflop_per_launch": roof["gflop_per_launch"],
+                               "algorithmic_tflops": roof["tflops"],
                                "algorithmic_bytes_per_launch": roof["bytes_per_launch"],
-                               "share_of_step_time": roof["total_ms"] / (ms * args.steps)}
-            if wino:   # `achieved` counts the direct form's 2*9*Cin*Cout FLOP per pixel; the kernel executes 16/36 of them
-                out["roofline"]["executed_tflops"] = roof["tflops"] * 16.0 / 36.0
-                out["roofline"]["frac_executed"] = roof["tflops"] * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS
-                out["roofline"]["note"] = ("algorithmic (direct-convolution) FLOP/s can exceed the f32 MFMA peak: Winograd F(2x2,3x3) "
-                                           "needs 16 instead of 36 multiply-adds per 2x2 output tile; frac_executed prices the "
-                                           "multiply-adds actually issued against the same peak")
-            # the next two MFMA-bound kernel families of the step, measured the same way (HIP events around every launch)
+                               "share_of_step_time": roof["total_ms"] / (ms * args.steps),
+                               "note": ("achieved/frac price the multiply-adds actually ISSUED to the f32 MFMA pipe; "
+                                        "algorithmic_tflops is the direct-convolution work (2*9*Cin*Cout per pixel, SURVEY.md 8(d)) "
+                                        "the same launches deliver" + (", 36/16 of the issued work under Winograd" if wino else ""))}
+            # whole step: every multiply-add issued by the MFMA kernels of the timed steps (host-side count per launch)
+            step_issued = ops.KERNEL_EVENTS.issued_timed / args.steps
+            out["roofline_step"] = {"bound": "mfma", "issued_tflop_per_step": step_issued / 1e12,
+                                    "achieved": step_issued / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": step_issued / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                    "algorithmic_tflop_per_step": ALGORITHMIC_GFLOP_PER_IMAGE.get(args.res, 0.0) * args.batch / 1e3
+                                    if not args.gan else None}
+            # the next kernel families of the step, measured the same way (HIP events around every launch) on one extra step
             names = {"conv3x3_wgrad_wino": "conv3x3_wgrad_wino_kernel (weight gradient of the stride-1 3x3 convs in the Winograd domain)",
-                     "gemm_f32": "gemm_f32_kernel (attention products incl. the fused softmax backward, 1x1 convs and their gradients)"}
+                     "gemm_f32": "gemm_f32_kernel (attention products incl. the fused softmax backward, 1x1 convs and their gradients)",
+                     "flash_attn": "flash_attn_{fwd,bwd} (fused attention: scores never leave the CU)",
+                     "groupnorm": "gn_* (GroupNorm(32, eps 1e-6) + swish, forward and backward incl. the folded skip gradient)"}
             out["roofline_others"] = []
             for key, r in others.items():
                 if r is None:
                     continue
-                e = {"kernel": names[key], "bound": "mfma", "achieved": r["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": r["tflops"] / PEAK_F32_MFMA_TFLOPS, "launches": r["launches"], "avg_launch_ms": r["avg_ms"],
+                e = {"kernel": names[key], "launches": r["launches"], "avg_launch_ms": r["avg_ms"], "total_ms": r["total_ms"],
                      "share_of_step_time": r["total_ms"] / extra_ms,
                      "measured_on": "one extra step after the timed region (HIP events around every launch of this family)"}
-                if key == "conv3x3_wgrad_wino":
-                    e["executed_tflops"] = r["tflops"] * 16.0 / 36.0
-                    e["frac_executed"] = e["executed_tflops"] / PEAK_F32_MFMA_TFLOPS
+                if key == "groupnorm":
+                    e.update({"bound": "hbm", "achieved": r["tbytes_per_s"] * 1e3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": r["tbytes_per_s"] * 1e3 / PEAK_HBM_GBS,
+                              "algorithmic_bytes_per_step": r["bytes_per_launch"] * r["launches"],
+                              "note": "algorithmic bytes = x read + y written (forward), x, dy (, skip gradient) read + dx written (backward)"})
+                else:
+                    k = 16.0 / 36.0 if key == "conv3x3_wgrad_wino" else 1.0
+                    e.update({"bound": "mfma", "achieved": r["tflops"] * k, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": r["tflops"] * k / PEAK_F32_MFMA_TFLOPS, "algorithmic_tflops": r["tflops"]})
                 out["roofline_others"].append(e)
+        out["peak_device_memory_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
         print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res, batch=2, steps=2)   # about 10 s of host work on 16 cores
+            # BASELINE.json configs[0] beside it: the reference's own CPU-runnable case (64x64, B=2, 10 steps)
+            out["cpu_baseline"]["config1"] = cpu_baseline(64, batch=2, steps=10)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

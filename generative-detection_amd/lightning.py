@@ -36,9 +36,13 @@ except Exception:  # noqa: BLE001
                 return p.device
             return torch.device("cpu")
 
-        def log(self, name, value, *args, **kwargs):
+        def log(self, name, value, *args, sync_dist=False, **kwargs):
+            """sync_dist=True (validation's `val/rec_loss`, src/models/autoencoder.py:359): mean over the ranks."""
             if torch.is_tensor(value):
                 value = value.detach()
+            if sync_dist:
+                from .parallel import all_reduce_mean
+                value = all_reduce_mean(value)
             self._logged[name] = value
 
         def log_dict(self, d, *args, **kwargs):

@@ -52,9 +52,16 @@ class _KernelEvents:
         self.on = False
         self.extra = False    # also bracket the secondary kernel families (bench.py: one extra step after the timed region)
         self.rec = {}
+        self.issued = 0.0
 
     def enable(self):
-        self.on, self.rec = True, {}
+        self.on, self.rec, self.issued = True, {}, 0.0
+
+    def count(self, issued_flops):
+        """Multiply-add work actually issued to the MFMA pipe by one launch (Winograd: 16/36 of the direct form); host
+        arithmetic only, summed over the timed steps for bench.py's whole-step MFMA fraction."""
+        if self.on:
+            self.issued += issued_flops
 
     def disable(self):
         self.on = False
@@ -66,7 +73,11 @@ class _KernelEvents:
         ev.record()
         return ev
 
-    def end(self, name, flops, ev0, nbytes=0.0):
+    def end(self, name, flops, ev0, nbytes=0.0, issued=None):
+        """flops = ALGORITHMIC work of the launch (direct form); issued = multiply-add work actually sent to the MFMA pipe
+        (defaults to flops)."""
+        if self.on:
+            self.issued += flops if issued is None else issued
         if ev0 is None:
             return
         ev1 = torch.cuda.Event(enable_timing=True)
@@ -80,9 +91,10 @@ class _KernelEvents:
             return None
         total_ms = sum(it[1].elapsed_time(it[2]) for it in items)
         flops = sum(it[0] for it in items)
+        nbytes = sum(it[3] for it in items)
         return {"launches": len(items), "total_ms": total_ms, "avg_ms": total_ms / len(items),
                 "gflop_per_launch": flops / len(items) / 1e9, "tflops": flops / total_ms / 1e9,
-                "bytes_per_launch": sum(it[3] for it in items) / len(items)}
+                "bytes_per_launch": nbytes / len(items), "tbytes_per_s": nbytes / total_ms / 1e9}
 
 
 KERNEL_EVENTS = _KernelEvents()
@@ -165,8 +177,19 @@ def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
                                    _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(), ho, wo, int(act), _lib.stream_ptr()),
                "conv3x3(mode=%d)" % mode)
     KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * ho * wo, tag,
-                      4.0 * (n * hi * wi * cin + n * ho * wo * cout * (2 if residual is not None else 1) + 9 * cin * cout))
+                      4.0 * (n * hi * wi * cin + n * ho * wo * cout * (2 if residual is not None else 1) + 9 * cin * cout),
+                      issued=_conv_issued(mode, n, hi, wi, ho, wo, cin, cout))
     return y
+
+
+def _conv_issued(mode, n, hi, wi, ho, wo, cin, cout):
+    """Multiply-add FLOP the direct kernels issue: modes 0/1/2 nine taps per output pixel; mode 3 (transposed stride-2
+    data gradient, inserted zeros skipped) nine per LOW-res pixel; modes 5/6 (Upsample conv by parity class) sixteen
+    pre-summed taps per low-res pixel."""
+    if mode in (5, 6, 3):
+        lo = n * min(hi, ho) * min(wi, wo)
+        return 2.0 * (9 if mode == 3 else 16) * cin * cout * lo
+    return 2.0 * 9 * cin * cout * n * ho * wo
 
 
 # Stride-1 3x3 convs by Winograd F(2x2, 3x3) (conv3x3_wino_f32.hip) when the shape allows; ODVAE_CONV_WINOGRAD=0 keeps
@@ -190,7 +213,8 @@ def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0):
     _lib.check(L.odvae_conv3x3_wino_f32(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
                                         y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino")
     KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
-                      4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout))
+                      4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
+                      issued=2.0 * 4 * cin * cout * n * h * w)   # F(2x2,3x3): 16 products per 2x2 tile = 4 per pixel
     return y
 
 
@@ -260,13 +284,16 @@ class _Conv3x3(Function):
                                                           dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
                            "conv3x3_wgrad_wino")
                 KERNEL_EVENTS.end("conv3x3_wgrad_wino", 2.0 * 9 * cin * cout * n * hi * wi, tag,
-                                  4.0 * (n * hi * wi * (cin + cout) + 9 * cin * cout))
+                                  4.0 * (n * hi * wi * (cin + cout) + 9 * cin * cout),
+                                  issued=2.0 * 4 * cin * cout * n * hi * wi)
             else:
                 need = L.odvae_conv3x3_wgrad_workspace_bytes(wmode, n, ho, wo, cin, cout)
                 wp, wn = _ws(need, x)
                 _lib.check(L.odvae_conv3x3_wgrad_f32(wmode, x.data_ptr(), dy.data_ptr(), n, hi, wi, cin, ho, wo, cout,
                                                      dw.data_ptr(), _lib.ptr(db), wp, wn, _lib.stream_ptr()),
                            "conv3x3_wgrad(mode=%d)" % wmode)
+                KERNEL_EVENTS.end("conv3x3_wgrad", 2.0 * 9 * cin * cout * n * ho * wo, None,
+                                  issued=_conv_issued(wmode, n, hi, wi, ho, wo, cin, cout))
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None
 
@@ -431,9 +458,12 @@ class _GroupNorm(Function):
         mean = torch.empty(n, groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty(n, groups, dtype=torch.float32, device=x.device)
         wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, groups), x)
+        tag = KERNEL_EVENTS.begin(secondary=True)
         _lib.check(L.odvae_groupnorm_fwd_f32(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps),
                                              int(swish), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn,
                                              _lib.stream_ptr()), "groupnorm_fwd")
+        # algorithmic traffic: x read once, y written once
+        KERNEL_EVENTS.end("groupnorm", 0.0, tag, 4.0 * 2 * n * h * w * c, issued=0.0)
         ctx.groups, ctx.swish = groups, int(swish)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.set_materialize_grads(False)   # an unused output's gradient stays None instead of a tensor of zeros
@@ -457,10 +487,13 @@ class _GroupNorm(Function):
         g = gamma.detach().contiguous()
         b = beta.detach().contiguous()
         wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, ctx.groups), x)
+        tag = KERNEL_EVENTS.begin(secondary=True)
         _lib.check(L.odvae_groupnorm_bwd_f32(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(),
                                              b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(),
                                              dg.data_ptr(), db.data_ptr(), _lib.ptr(dskip), wp, wn, _lib.stream_ptr()),
                    "groupnorm_bwd")
+        # algorithmic traffic: x, dy (and the folded skip gradient) read once, dx written once
+        KERNEL_EVENTS.end("groupnorm", 0.0, tag, 4.0 * (3 + (dskip is not None)) * n * h * w * c, issued=0.0)
         return dx, dg, db, None, None, None, None
 
 

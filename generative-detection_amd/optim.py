@@ -15,7 +15,9 @@ _ALIGN = 64  # floats; keeps every parameter view 256-byte aligned (float4 kerne
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps))
+        # weight_decay / amsgrad are carried (at the values the reference runs with) so that the saved param_groups read
+        # like torch.optim.Adam's; nothing else is implemented
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._flat = None
         self._steps = 0
         self._clip = None       # device [norm, coef] written by clip_grad_norm_
@@ -106,7 +108,10 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:   # PL's automatic optimisation hands training_step + backward in as the closure
+            with torch.enable_grad():
+                loss = closure()
         f = self.materialize()
         self._ensure_grad_views()
         g0 = self.param_groups[0]
@@ -135,6 +140,42 @@ class FusedAdam(torch.optim.Optimizer):
         from . import ops
         ops.PACK_CACHE.bump()   # parameters changed under torch's version counters: conv weight packs are stale
         return loss
+
+
+    # ---- checkpoint interchange: torch.optim.Adam's state layout ------------------------------------------------------------
+    def state_dict(self):
+        """{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} exactly as torch.optim.Adam writes it
+        (Lightning stores this under `optimizer_states`), so a resume -- here or under the reference's Adam -- keeps the
+        moments and the bias-correction step.  Parameters that never received a gradient carry no state, as in torch."""
+        if self._flat is None:
+            return super().state_dict()
+        f = self._flat
+        self.state.clear()
+        for i, (p, o) in enumerate(zip(f["params"], f["offsets"])):
+            if self._counts[i] > 0:
+                n = p.numel()
+                self.state[p] = {"step": torch.tensor(float(self._counts[i])),
+                                 "exp_avg": f["m"][o:o + n].view(p.shape).clone(),
+                                 "exp_avg_sq": f["v"][o:o + n].view(p.shape).clone()}
+        out = super().state_dict()
+        self.state.clear()   # the arenas stay the only live copy
+        return out
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)   # torch maps indices -> parameters and casts the moments to their device
+        f = self.materialize()
+        f["m"].zero_()
+        f["v"].zero_()
+        for i, (p, o) in enumerate(zip(f["params"], f["offsets"])):
+            st = self.state.get(p)
+            self._counts[i] = 0
+            if st:
+                n = p.numel()
+                f["m"][o:o + n].copy_(st["exp_avg"].reshape(-1))
+                f["v"][o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self._counts[i] = int(round(float(st["step"])))
+        self._steps = max(self._counts) if self._counts else 0
+        self.state.clear()
 
 
 def make_adam(params, lr, betas):

@@ -16,9 +16,13 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, process_group=None, bucket_mb=32.0):
+    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False):
+        """prescaled=True: the caller back-propagates `loss * inv_world` (trainer.Trainer does), so the summed buckets
+        already ARE the mean and finish() needs no averaging pass over the arena (284 MB for optimizer 0)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.inv_world = 1.0 / self.world
+        self.prescaled = bool(prescaled)
         self.optimizer = optimizer
         if hasattr(optimizer, "param_slices"):
             slices = optimizer.param_slices()
@@ -91,15 +95,16 @@ class GradReducer:
 
     def finish(self):
         """Issue the collectives of buckets that only some of their parameters reached (same set on every rank,
-        since control flow depends on global_step only), wait for all, average."""
+        since control flow depends on global_step only) and wait for all.  The mean comes for free when the loss was
+        pre-scaled by 1/world (`prescaled`); otherwise the reduced buckets are averaged here."""
         for b in sorted(self._touched_buckets - self._launched, reverse=True):
             self._launch(b)
         for w in self._works:
             w.wait()
-        inv = 1.0 / self.world
-        for b in self.launch_order:
-            s, e = self.buckets[b]
-            self.arena[s:e].mul_(inv)
+        if not self.prescaled:
+            for b in self.launch_order:
+                s, e = self.buckets[b]
+                self.arena[s:e].mul_(self.inv_world)
         self._pending = None
 
     # ---- start-up ------------------------------------------------------------------------------------------------------
@@ -108,3 +113,18 @@ class GradReducer:
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
+        # raw .data writes bump no version counter: conv weight packs cached from an earlier forward are stale now
+        from . import ops
+        ops.PACK_CACHE.bump()
+
+
+def all_reduce_mean(value, group=None):
+    """Mean over ranks of a scalar (python number or 0-d tensor): the `sync_dist=True` of `self.log`
+    (src/models/autoencoder.py:359).  Identity when no process group is active."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    t = value.detach().clone().float() if torch.is_tensor(value) else torch.tensor(float(value))
+    if dist.get_backend(group) == "nccl" and not t.is_cuda:
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t / dist.get_world_size(group)

@@ -34,7 +34,8 @@ class Trainer:
         self.reducers = None
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
                                          and torch.distributed.get_world_size() > 1):
-            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb) for o in opts]
+            # the mean over ranks rides in the loss scale (training_batch), not in a pass over the gradient arena
+            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb, prescaled=True) for o in opts]
             self.reducers[0].broadcast_parameters(model)
 
     # PL-1.9 toggle_optimizer: parameters owned by the *other* optimizers stop requiring grad; parameters in no
@@ -70,9 +71,10 @@ class Trainer:
                 red = self.reducers[idx] if self.reducers else None
                 if red is not None:
                     red.prepare_for_backward()
-                loss.backward()
-                if red is not None:
+                    (loss * red.inv_world).backward()   # sum over ranks of grad(loss / world) = DDP's mean gradient
                     red.finish()
+                else:
+                    loss.backward()
                 if self.clip:
                     if hasattr(opt, "clip_grad_norm_"):
                         opt.clip_grad_norm_(self.clip)

@@ -73,7 +73,8 @@ def _worker(rank, world, port, out_dir):
     red = trainer.reducers[0]
     loss = model.training_step((full_x[shard], full_y[shard]), 0, 0)
     red.prepare_for_backward()
-    loss.backward()
+    assert red.prescaled                     # the Trainer's reducers take the mean through the loss scale
+    (loss * red.inv_world).backward()
     order = list(red.launch_order)
     red.finish()
     grads = {n: p.grad.clone() for n, p in model.gen.named_parameters()}
@@ -81,7 +82,22 @@ def _worker(rank, world, port, out_dir):
     # --- several batches through the trainer ---
     for i in range(3):
         trainer.training_batch((full_x[shard] + i, full_y[shard]), i)
-    torch.save({"grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
+    # sync_dist=True of self.log (validation's val/rec_loss, autoencoder.py:359): mean over ranks
+    from odvae_amd.lightning import LightningModule
+    lm = LightningModule()
+    lm.log("val/rec_loss", torch.tensor(float(rank + 1)), sync_dist=True)
+    lm.log("local", torch.tensor(float(rank + 1)))
+    synced, local = float(lm.logged_metrics["val/rec_loss"]), float(lm.logged_metrics["local"])
+    # a generic (non-prescaled) reducer still averages in finish()
+    net2 = TinyNet()
+    opt2 = torch.optim.SGD(net2.parameters(), lr=0.1)
+    red2 = GradReducer(opt2, bucket_mb=0.02)
+    red2.broadcast_parameters(net2)
+    red2.prepare_for_backward()
+    net2(full_x[shard]).pow(2).mean().backward()
+    red2.finish()
+    g2 = torch.cat([p.grad.reshape(-1) for p in net2.parameters()]).clone()
+    torch.save({"synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
                 "global_step": model._global_step}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -110,3 +126,9 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     assert r0["global_step"] == 6 and r1["global_step"] == 6
+    assert r0["synced"] == r1["synced"] == 1.5 and (r0["local"], r1["local"]) == (1.0, 2.0)
+    ref2 = TinyNet()
+    ref2.load_state_dict(r0["sd2"])
+    ref2(full_x).pow(2).mean().backward()
+    want = torch.cat([p.grad.reshape(-1) for p in ref2.parameters()])
+    assert torch.allclose(r0["g2"], want, atol=1e-6) and torch.equal(r0["g2"], r1["g2"])
