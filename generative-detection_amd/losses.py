@@ -89,6 +89,20 @@ class LPIPSWithDiscriminator(nn.Module):
         self.discriminator_weight = disc_weight
         self.disc_conditional = disc_conditional
 
+    def _check_perceptual_weights(self):
+        """Once per loss object: the reference cannot even be constructed without the real LPIPS weights ([UPSTREAM]
+        LPIPS.__init__ downloads them); here a run with perceptual_weight > 0 on the construction-time stand-ins is
+        allowed (benchmarks, tests) but never silent."""
+        if getattr(self, "_perceptual_checked", False):
+            return
+        self._perceptual_checked = True
+        if self.perceptual_loss.has_synthetic_weights():
+            import warnings
+            warnings.warn("perceptual_weight = %g but loss.perceptual_loss still holds its seeded SYNTHETIC weights: the "
+                          "perceptual term is LPIPS-shaped, not LPIPS. Load a checkpoint carrying loss.perceptual_loss.* or call "
+                          "loss.perceptual_loss.load_weights(vgg16=..., lins=...) (torchvision vgg16 + taming vgg.pth)."
+                          % self.perceptual_weight, RuntimeWarning, stacklevel=3)
+
     def calculate_adaptive_weight(self, nll_loss, g_loss, last_layer=None):
         if last_layer is None:
             last_layer = self.last_layer[0]
@@ -223,6 +237,7 @@ class PoseLoss(LPIPSWithDiscriminator):
             s = torch.zeros(n, device=inputs_rgb.device)
         p_loss = None
         if self.perceptual_weight > 0:
+            self._check_perceptual_weights()
             p_loss = self.perceptual_loss(ops.mul_mask(inputs_rgb, mask_2d_bbox), ops.mul_mask(recon_rgb, mask_2d_bbox))
             s = s + self.perceptual_weight * p_loss.reshape(n) * chw
         return s, chw

@@ -63,46 +63,76 @@ class NLayerDiscriminator(nn.Module):
         return self.main(input)
 
 
-VGG16_CFG = [(64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512)]
+# [UPSTREAM] taming/modules/losses/lpips.py: torchvision vgg16().features cut into five nn.Sequential slices whose
+# members keep their feature index as name; entries: int c = Conv2d(->c, 3x3, pad 1), "R" = ReLU, "M" = MaxPool2d(2, 2)
+VGG16_FEATURES = [64, "R", 64, "R", "M", 128, "R", 128, "R", "M", 256, "R", 256, "R", 256, "R", "M",
+                  512, "R", 512, "R", 512, "R", "M", 512, "R", 512, "R", 512, "R"]
+VGG16_SLICE_BOUNDS = [(0, 4), (4, 9), (9, 16), (16, 23), (23, 30)]
 
 
-class LPIPSStyle(nn.Module):
-    """LPIPS structure with whatever weights are loaded into it (state_dict-compatible with odvae_amd.gan.LPIPSStyle)."""
-
+class _ScalingLayer(nn.Module):
     def __init__(self):
         super().__init__()
         self.register_buffer("shift", torch.tensor([-.030, -.088, -.188])[None, :, None, None])
         self.register_buffer("scale", torch.tensor([.458, .448, .450])[None, :, None, None])
-        self.slices = nn.ModuleList()
-        cin = 3
-        for widths in VGG16_CFG:
-            convs = nn.ModuleList()
-            for cout in widths:
-                convs.append(nn.Conv2d(cin, cout, 3, padding=1))
-                cin = cout
-            self.slices.append(convs)
-        self.lins = nn.ModuleList([nn.Conv2d(w[-1], 1, 1, bias=False) for w in VGG16_CFG])
+
+    def forward(self, inp):
+        return (inp - self.shift) / self.scale
+
+
+class _NetLinLayer(nn.Module):
+    def __init__(self, chn_in, chn_out=1):
+        super().__init__()
+        self.model = nn.Sequential(nn.Dropout(), nn.Conv2d(chn_in, chn_out, 1, stride=1, padding=0, bias=False))
+
+
+class _Vgg16(nn.Module):
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for v in VGG16_FEATURES:
+            if v == "R":
+                layers.append(nn.ReLU(inplace=False))
+            elif v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers.append(nn.Conv2d(cin, v, kernel_size=3, padding=1))
+                cin = v
+        for k, (lo, hi) in enumerate(VGG16_SLICE_BOUNDS):
+            sl = nn.Sequential()
+            for x in range(lo, hi):
+                sl.add_module(str(x), layers[x])
+            setattr(self, "slice%d" % (k + 1), sl)
+
+    def forward(self, x):
+        outs = []
+        for k in range(5):
+            x = getattr(self, "slice%d" % (k + 1))(x)
+            outs.append(x)
+        return outs
+
+
+class LPIPSStyle(nn.Module):
+    """[UPSTREAM] taming LPIPS structure and state_dict keys (scaling_layer.*, net.slice{k}.{idx}.*, lin{k}.model.1.weight)
+    with whatever weights are loaded into it."""
+
+    def __init__(self):
+        super().__init__()
+        self.scaling_layer = _ScalingLayer()
+        self.chns = [64, 128, 256, 512, 512]
+        self.net = _Vgg16()
+        for k, c in enumerate(self.chns):
+            setattr(self, "lin%d" % k, _NetLinLayer(c))
         for p in self.parameters():
             p.requires_grad = False
 
-    def features(self, x):
-        h = (x - self.shift) / self.scale
-        outs = []
-        for k, convs in enumerate(self.slices):
-            if k > 0:
-                h = F.max_pool2d(h, kernel_size=2, stride=2)
-            for conv in convs:
-                h = F.relu(conv(h))
-            outs.append(h)
-        return outs
-
     def forward(self, input, target):
-        f0, f1 = self.features(input), self.features(target)
+        f0, f1 = self.net(self.scaling_layer(input)), self.net(self.scaling_layer(target))
         val = 0
-        for k in range(len(VGG16_CFG)):
+        for k in range(len(self.chns)):
             n0 = f0[k] / (torch.sqrt(torch.sum(f0[k] ** 2, dim=1, keepdim=True)) + 1e-10)
             n1 = f1[k] / (torch.sqrt(torch.sum(f1[k] ** 2, dim=1, keepdim=True)) + 1e-10)
-            val = val + self.lins[k]((n0 - n1) ** 2).mean([2, 3], keepdim=True)
+            val = val + getattr(self, "lin%d" % k).model((n0 - n1) ** 2).mean([2, 3], keepdim=True)
         return val
 
 

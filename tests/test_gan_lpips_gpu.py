@@ -187,3 +187,46 @@ def test_lpips_style_matches_oracle(hip_lib):
     close(d, d_ref, 1e-3, "lpips fwd")
     d.sum().backward()
     close(x1d.grad, x1r.grad, 5e-3, "lpips dx")
+
+
+def test_lpips_from_upstream_keyed_checkpoint(hip_lib, tmp_path):
+    """A checkpoint carrying `loss.perceptual_loss.*` in the UPSTREAM key scheme goes through `ckpt_path` into the HIP model and
+    straight into the oracle; both then give the same perceptual distance and input gradient (reference:
+    src/modules/losses/contperceptual.py:3,5; src/models/autoencoder.py:97-98)."""
+    import os
+    import warnings
+    from test_checkpoint import YAML, _oracle, synthetic_upstream_lpips_state
+    from odvae_amd import synthetic
+    from odvae_amd.config import instantiate_from_config
+    sd = synthetic_upstream_lpips_state(seed=21)
+    torch.manual_seed(4)
+    ref = _oracle()
+    full = ref.state_dict()
+    for k, v in sd.items():
+        full["loss.perceptual_loss." + k] = v
+    path = os.path.join(tmp_path, "last.ckpt")
+    torch.save({"state_dict": full}, path)
+    ref.load_state_dict(torch.load(path)["state_dict"], strict=True)
+    mcfg, _ = synthetic.model_config(YAML, latent_hw=4, ch=32, perceptual_weight=1.0)
+    mcfg.params["ckpt_path"] = path
+    model = instantiate_from_config(mcfg).to(DEV)
+    lp, lp_ref = model.loss.perceptual_loss.eval(), ref.loss.perceptual_loss.eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")            # real (loaded) weights: the synthetic-weights warning must stay quiet
+        model.loss._check_perceptual_weights()
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    x1 = (x0 + 0.25 * torch.randn(2, 3, 64, 64, generator=g)).clamp(-1, 1)
+    x1r = x1.clone().requires_grad_(True)
+    d_ref = lp_ref(x0, x1r)
+    d_ref.sum().backward()
+    x1d = x1.to(DEV).requires_grad_(True)
+    d = lp(x0.to(DEV), x1d)
+    close(d, d_ref, 1e-3, "lpips(ckpt) fwd")
+    d.sum().backward()
+    close(x1d.grad, x1r.grad, 5e-3, "lpips(ckpt) dx")
+    # and a fresh loss with perceptual_weight > 0 on the stand-in weights does warn
+    mcfg2, _ = synthetic.model_config(YAML, latent_hw=4, ch=32, perceptual_weight=1.0)
+    model2 = instantiate_from_config(mcfg2).to(DEV)
+    with pytest.warns(RuntimeWarning, match="SYNTHETIC"):
+        model2.loss._check_perceptual_weights()
