@@ -84,3 +84,30 @@ def build_model(yaml_path, batch_size_for_lr=None, **kw):
     bs = batch_size_for_lr if batch_size_for_lr is not None else cfg.data.params.batch_size
     model.learning_rate = 1 * 1 * bs * cfg.model.base_learning_rate  # accumulate * ngpu * bs * base_lr (train.py:383)
     return model
+
+
+def fill_state_procedural(module, seed=23):
+    """Deterministic weights that depend only on (seed, state_dict key, shape) -- not on torch's init routines or on the
+    construction order of a module tree -- so committed fixtures (tests/golden/make_op_fixtures.py) can name their weights
+    without storing them.  Matrices ~ N(0, 1/fan_in), norm scales ~ 1 + 0.1 N, biases ~ 0.05 N; integer buffers untouched."""
+    import zlib
+    sd = module.state_dict()
+    with torch.no_grad():
+        for key in sorted(sd.keys()):
+            t = sd[key]
+            if not t.is_floating_point() or key.startswith("loss.perceptual_loss.scaling_layer"):
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(key.encode()) + 7919 * seed) % (2 ** 31))
+            r = torch.randn(t.shape, generator=g)
+            if key.endswith("running_var"):
+                v = 1.0 + 0.1 * r.abs()
+            elif t.dim() >= 2:
+                v = r / float(max(1, t[0].numel())) ** 0.5
+            elif "norm" in key and key.endswith("weight"):
+                v = 1.0 + 0.1 * r
+            elif t.dim() == 0:
+                v = torch.zeros(())
+            else:
+                v = 0.05 * r
+            t.copy_(v.to(t.dtype))
+    return module

@@ -65,3 +65,31 @@ def test_reference_shape_known_answers():
     # attention sits at level 2 in both halves (curr_res bookkeeping)
     enc = Encoder(**dd)
     assert [len(s.attn) for s in enc.down] == [0, 0, 2, 0, 0]
+
+
+def _load_gen():
+    spec = importlib.util.spec_from_file_location("make_op_fixtures", os.path.join(GOLD, "make_op_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_oracle_reproduces_op_fixtures():
+    """the committed per-op vectors are what the oracle's torch-CPU ops give today."""
+    g = np.load(os.path.join(GOLD, "ops_tiny.npz"))
+    now = _load_gen().op_cases()
+    assert set(now.keys()) == set(g.files)
+    for k, v in now.items():
+        assert np.allclose(v, g[k], rtol=1e-4, atol=1e-5), k
+
+
+def test_oracle_reproduces_model_ch32_fixture():
+    """width-reduced model, one training step's outputs, loss terms and gradient norms."""
+    g = np.load(os.path.join(GOLD, "model_ch32.npz"))
+    now = _load_gen().model_case()
+    assert set(now.keys()) == set(g.files)
+    for k, v in now.items():
+        if v.dtype.kind in "US":
+            assert list(v) == list(g[k]), k
+        else:
+            assert np.allclose(v, g[k], rtol=5e-4, atol=1e-5 * max(1.0, float(np.abs(g[k]).max()))), k
