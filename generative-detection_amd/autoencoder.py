@@ -54,6 +54,21 @@ class AutoencoderKL(LightningModule):
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
+    def set_precision(self, precision):
+        """The trainer's `precision` (configs/autoencoder/pose/autoencoder_kl_16x16x16.yaml:139; PL-1.9 accepts 32, "32", 16, "bf16"):
+        32 = f32 everywhere; "bf16" = mixed precision -- bf16 activations inside Encoder / Decoder on the bf16 MFMA kernels, f32
+        master weights, gradients, statistics, latent, reconstruction and losses.  fp16 is not offered (no loss scaler here)."""
+        p = str(precision).lower()
+        if p in ("32", "32-true", "fp32"):
+            dt = torch.float32
+        elif p in ("bf16", "bf16-mixed"):
+            dt = torch.bfloat16
+        else:
+            raise ValueError("precision %r: this build computes in 32 (f32) or bf16 (mixed precision)" % (precision,))
+        self.encoder.compute_dtype = dt
+        self.decoder.compute_dtype = dt
+        return self
+
     def init_from_ckpt(self, path, ignore_keys=list()):
         sd = torch.load(path, map_location="cpu")["state_dict"]
         for k in list(sd.keys()):

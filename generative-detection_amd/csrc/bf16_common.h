@@ -1,0 +1,57 @@
+// bf16 helpers for the mixed-precision path (BASELINE.json configs[4]: bf16 activations in HBM, fp32 master weights,
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16).  gfx950 only.
+#pragma once
+#include "common.h"
+
+typedef unsigned short bf16_t;                                   // raw bits in HBM / LDS
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));      // one MFMA A/B fragment (4 VGPRs)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+// round to nearest even, NaN kept quiet (what torch's .to(bfloat16) does)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// two floats -> one dword of two bf16 (lo in bits 0..15); v_cvt_pk_bf16_f32 rounds to nearest even
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+#else
+  (void)lo; (void)hi; return 0;
+#endif
+}
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+// D(32x32) += A(32x16) * B(16x32), bf16 in, f32 accumulate.  lane l (r = l&31, h = l>>5) supplies A[row r][k = 8h+j] and
+// B[k = 8h+j][col r], j = 0..7; D register i of lane l is D[row (i&3) + 8(i>>2) + 4h][col r]  (tools/tr_probe.hip)
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  (void)a; (void)b; return c;
+#endif
+}
+__device__ __forceinline__ bf16x8 frag_from_u32x4(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major.  Lane 4q+p of
+// the group passes the LDS address of (row q, column 4p); lane i receives column i of rows 0..3 (element q = row q).
+// EXEC must be all ones.  Address must be 8-byte aligned.
+__device__ __forceinline__ s16x4 lds_read_tr16(const bf16_t* lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_addr);
+#else
+  (void)lds_addr; return s16x4{0, 0, 0, 0};
+#endif
+}
+__device__ __forceinline__ bf16x8 frag_from_tr(s16x4 lo, s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}

@@ -1,0 +1,340 @@
+// 3x3 / 1x1 convolution, NHWC bf16 activations, fp32 accumulate on v_mfma_f32_32x32x16_bf16, gfx950.
+// Mixed-precision path of BASELINE.json configs[4] (trainer `precision: bf16`; reference knobs: configs/autoencoder/pose/
+// autoencoder_kl_16x16x16.yaml:139 `precision`, train.py:521).  Same layer set as conv3x3_f32.hip:
+//   MODE 0  3x3 stride 1 pad 1 (ResnetBlock.conv1/conv2, conv_in, conv_out; data gradient = MODE 0 on the flipped pack)
+//   MODE 1  Downsample: pad (0,1,0,1) + 3x3 stride 2
+//   MODE 2  Upsample: nearest 2x + 3x3 stride 1 (the 4x intermediate is never formed: the gather reads x[y>>1][x>>1])
+//   MODE 3  data gradient of MODE 1 (stride-2 transposed conv; taps that would hit an inserted zero are masked)
+//   MODE 4  1x1 (nin_shortcut, AttnBlock q/k/v/proj_out, and their data gradients): pixels flattened to [M/16][16]
+// [UPSTREAM] ldm/modules/diffusionmodules/model.py via src/modules/autoencodermodules/feat_encoder.py:4, feat_decoder.py:4.
+//
+// Implicit GEMM with the OUTPUT CHANNEL on the MFMA row and the PIXEL on the lane:  D[co][px] += W[co][ci] * X[ci][px].
+//   A fragment (weights): lane (r, h) holds W[co0 + r][ci0 + 8h .. +7]  -- one coalesced 16-byte load from the pack
+//                         [tap][CinP/16][CoutP/32][64 lanes][8], L2 -> registers, no LDS
+//   B fragment (pixels):  lane (r, h) holds X[pixel r][ci0 + 8h .. +7]  -- one ds_read_b128 from the halo patch
+//   D: lane = pixel, registers = 4-channel runs -> the epilogue packs to bf16 and writes 8 bytes per lane and run.
+// Block = 8x16 output pixels x BCO output channels, 4 waves; per KC input channels the halo patch [halo px][KC + 8] is
+// staged once (double-buffered, branch-free buffer loads with hardware zero fill), ONE barrier per chunk.
+#include "bf16_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;
+
+struct ConvB {
+  const bf16_t* x;         // [N][Hi][Wi][Cin]
+  const bf16_t* wpk;       // [taps][CinP/16][CoutP/32][64][8]
+  const float* bias;       // [Cout] or null
+  const bf16_t* residual;  // [N][Ho][Wo][Cout] bf16 or null
+  void* y;                 // [N][Ho][Wo][Cout] bf16 (out_f32 = 0) or f32
+  int N, Hi, Wi, Cin, Ho, Wo, Cout, CinP, CoutP;
+  int tiles_x, tiles_y, out_f32;
+};
+
+template <int MODE> struct HaloB;
+template <> struct HaloB<0> { static constexpr int H = TH + 2, W = TW + 2, TAPS = 9; };
+template <> struct HaloB<1> { static constexpr int H = 2 * TH + 1, W = 2 * TW + 1, TAPS = 9; };
+template <> struct HaloB<2> { static constexpr int H = TH / 2 + 2, W = TW / 2 + 2, TAPS = 9; };
+template <> struct HaloB<3> { static constexpr int H = TH / 2 + 1, W = TW / 2 + 1, TAPS = 9; };
+template <> struct HaloB<4> { static constexpr int H = TH, W = TW, TAPS = 1; };
+
+template <int MODE>
+__device__ __forceinline__ int halo_index_b(int r, int c, int kh, int kw, bool& ok) {
+  ok = true;
+  if (MODE == 0) return (r + kh) * HaloB<0>::W + (c + kw);
+  if (MODE == 1) return (2 * r + kh) * HaloB<1>::W + (2 * c + kw);
+  if (MODE == 2) return ((r + kh + 1) >> 1) * HaloB<2>::W + ((c + kw + 1) >> 1);
+  if (MODE == 4) return r * TW + c;
+  ok = (((r + kh) | (c + kw)) & 1) == 0;
+  return ((r + kh) >> 1) * HaloB<3>::W + ((c + kw) >> 1);
+}
+template <int MODE>
+__device__ __forceinline__ void halo_origin_b(int oy0, int ox0, int& iy0, int& ix0) {
+  if (MODE == 0) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
+  else if (MODE == 1) { iy0 = 2 * oy0; ix0 = 2 * ox0; }
+  else if (MODE == 4) { iy0 = oy0; ix0 = ox0; }
+  else { iy0 = oy0 / 2 - 1; ix0 = ox0 / 2 - 1; }
+}
+
+// WCT x WPT MFMA tiles per wave (channel tiles x pixel tiles), WAVES_CO x WAVES_PX waves; WAVES_PX * WPT = 4 pixel tiles
+template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
+  static_assert(WAVES_CO * WAVES_PX == 4 && WAVES_PX * WPT == 4, "tile layout");
+  constexpr int BCO = WAVES_CO * WCT * 32;
+  constexpr int HS = KC + 8;                           // halo row stride in bf16 (16 bytes of padding: conflict-free b128 reads)
+  constexpr int HPIX = HaloB<MODE>::H * HaloB<MODE>::W;
+  constexpr int VC = KC / 8;                           // 16-byte vectors per halo pixel
+  constexpr int HALO_V = HPIX * VC;
+  constexpr int HALO_IT = (HALO_V + 255) / 256;
+  constexpr int TAPS = HaloB<MODE>::TAPS;
+  constexpr int KS = KC / 16;                          // MFMA k-steps per tap and chunk
+  constexpr int NIT = TAPS * KS;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * HPIX * HS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave / WAVES_PX, wpx = wave % WAVES_PX;
+  const int li = lane & 31, h = lane >> 5;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int co0 = blockIdx.y * BCO;
+  int iy0, ix0;
+  halo_origin_b<MODE>(oy0, ox0, iy0, ix0);
+
+  const int esz = p.out_f32 ? 4 : 2;
+  const unsigned OOB = 0x7FFFFFF0u;
+  // this lane's pixel in each of its pixel tiles (column of the MFMA result)
+  unsigned pixoff[WPT];      // element offset of the output pixel, or OOB
+  int prr[WPT], pcc[WPT];
+#pragma unroll
+  for (int pt = 0; pt < WPT; ++pt) {
+    const int pm = (wpx * WPT + pt) * 32 + li;
+    prr[pt] = pm / TW; pcc[pt] = pm % TW;
+    const int oy = oy0 + prr[pt], ox = ox0 + pcc[pt];
+    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
+  }
+
+  // accumulators start at bias + residual: the epilogue is stores only
+  f32x16 acc[WCT][WPT];
+  {
+    const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) {
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.residual) {   // Cout % 4 == 0 is checked on the host when a residual is given
+            const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
+            rv[0] = bf16_lo(v.x); rv[1] = bf16_hi(v.x); rv[2] = bf16_lo(v.y); rv[3] = bf16_hi(v.y);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ct][pt][4 * g + j] = bv[j] + rv[j];
+        }
+      }
+  }
+
+  // ---- halo fetch: branch-free buffer loads, out-of-image / past-Cin lanes read 0 --------------------------------------
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin), 0, p.Hi * p.Wi * p.Cin * 2, 0x00020000);
+  u32x4 hreg[HALO_IT];
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      const int hp = f / VC, q = f % VC;
+      const int iy = iy0 + hp / HaloB<MODE>::W, ix = ix0 + hp % HaloB<MODE>::W;
+      const int c = c0 + 8 * q;
+      const bool ok = f < HALO_V && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin;
+      const unsigned voff = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + c) * 2) : OOB;
+      hreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+    }
+  };
+  auto store_halo = [&](bf16_t* Hs) {
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int f = tid + 256 * i;
+      if (f < HALO_V) *reinterpret_cast<u32x4*>(Hs + (f / VC) * HS + 8 * (f % VC)) = hreg[i];
+    }
+  };
+
+  // ---- operand fetch ------------------------------------------------------------------------------------------------------
+  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wpk);
+  const int KT = p.CinP / 16, CT = p.CoutP / 32;
+  const int ct0 = co0 / 32 + wco * WCT;
+  auto load_a = [&](int ch, int it, bf16x8 (&a)[WCT]) {   // weight fragments of step `it` of chunk `ch`
+    const int tap = it / KS, ks = it % KS;
+    const int64_t base = ((int64_t)(tap * KT + ch * KS + ks) * CT + ct0) * 64 + lane;
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(wq[base + ct * 64]);
+  };
+  auto load_b = [&](const bf16_t* Hs, int it, bf16x8 (&b)[WPT]) {
+    const int tap = it / KS, ks = it % KS;
+    const int kh = TAPS == 1 ? 0 : tap / 3, kw = TAPS == 1 ? 0 : tap % 3;
+#pragma unroll
+    for (int pt = 0; pt < WPT; ++pt) {
+      bool ok;
+      const int hp = halo_index_b<MODE>(prr[pt], pcc[pt], kh, kw, ok);
+      u32x4 v = *reinterpret_cast<const u32x4*>(Hs + hp * HS + 16 * ks + 8 * h);
+      if (MODE == 3 && !ok) v = u32x4{0u, 0u, 0u, 0u};
+      b[pt] = frag_from_u32x4(v);
+    }
+  };
+
+  const int nchunks = p.CinP / KC;
+  bf16x8 ac[WCT], an[WCT], an2[WCT], bc[WPT], bn[WPT];
+  auto load_a_step = [&](int ch, int it, bool more, bf16x8 (&a)[WCT]) {   // step `it` may run into chunk ch + 1
+    if (it < NIT) load_a(ch, it, a);
+    else if (more) load_a(ch + 1, it - NIT, a);
+  };
+  load_halo(0);
+  load_a(0, 0, ac);
+  load_a_step(0, 1, nchunks > 1, an);
+  store_halo(smem);
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const bf16_t* Hs = smem + (ch & 1) * HPIX * HS;
+    const bool more = ch + 1 < nchunks;
+    if (more) load_halo((ch + 1) * KC);
+    load_b(Hs, 0, bc);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      load_a_step(ch, it + 2, more, an2);       // weights two steps ahead (L2 latency), pixels one step ahead (LDS)
+      if (it + 1 < NIT) load_b(Hs, it + 1, bn);
+#pragma unroll
+      for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(ac[ct], bc[pt], acc[ct][pt]);
+#pragma unroll
+      for (int ct = 0; ct < WCT; ++ct) { ac[ct] = an[ct]; an[ct] = an2[ct]; }
+#pragma unroll
+      for (int pt = 0; pt < WPT; ++pt) bc[pt] = bn[pt];
+    }
+    if (more) store_halo(smem + ((ch + 1) & 1) * HPIX * HS);
+    __syncthreads();
+  }
+
+  // ---- epilogue: stores only ------------------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      static_cast<char*>(p.y) + (int64_t)n * p.Ho * p.Wo * p.Cout * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
+#pragma unroll
+  for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int pt = 0; pt < WPT; ++pt) {
+        if (p.out_f32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ct][pt][4 * g + j]), yrsrc, off, 0, 0);
+          }
+        } else {   // Cout % 4 == 0 (host check): a 4-channel run is inside or outside as a whole
+          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+          u32x2 v;
+          v.x = pack_bf16x2(acc[ct][pt][4 * g + 0], acc[ct][pt][4 * g + 1]);
+          v.y = pack_bf16x2(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
+        }
+      }
+    }
+}
+
+// OIHW f32 (kh x kw = 3x3 or 1x1) -> bf16 fragment packs.
+//   fwd:   reduce over Cin, rows = Cout:   W[tap][co][ci]
+//   dgrad: reduce over Cout, rows = Cin:   W'[tap][ci][co] = w[co][ci][flip(tap)]   (MODE 0 / 4 data gradient; MODE 3 uses
+//          the same flipped pack: dx = transposed conv of dy)
+// layout [tap][RP/16][OP/32][lane 64][8]: lane (r, h) element j = W[row 32*ot + r][k = 16*kt + 8h + j]
+__global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
+                                      bf16_t* __restrict__ fwd, int RP_f, int OP_f, bf16_t* __restrict__ dgr, int RP_d, int OP_d) {
+  const int64_t nf = fwd ? (int64_t)taps * RP_f * OP_f : 0;
+  const int64_t nd = dgr ? (int64_t)taps * RP_d * OP_d : 0;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd; idx += (int64_t)gridDim.x * blockDim.x) {
+    const bool f = idx < nf;
+    int64_t r = f ? idx : idx - nf;
+    const int RP = f ? RP_f : RP_d, OP = f ? OP_f : OP_d;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int ot = (int)(r % (OP / 32)); r /= (OP / 32);
+    const int kt = (int)(r % (RP / 16)); const int tap = (int)(r / (RP / 16));
+    const int row = 32 * ot + (lane & 31), k = 16 * kt + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (f) { if (row < Cout && k < Cin) v = w[((int64_t)row * Cin + k) * taps + tap]; }
+    else   { if (row < Cin && k < Cout) v = w[((int64_t)k * Cin + row) * taps + (taps - 1 - tap)]; }
+    (f ? fwd : dgr)[f ? idx : idx - nf] = f32_to_bf16(v);
+  }
+}
+
+int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX>
+void launch_cfg(const ConvB& p, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX>), grid, dim3(256), 0, st, p);
+}
+
+template <int MODE, int KC>
+void launch_by_cout(const ConvB& p, hipStream_t st) {
+  const int tiles = p.N * p.tiles_x * p.tiles_y;
+  if (p.Cout > 64)      launch_cfg<MODE, KC, 2, 2, 2, 2>(p, dim3(tiles, ceil_div(p.Cout, 128)), st);
+  else if (p.Cout > 32) launch_cfg<MODE, KC, 2, 1, 1, 4>(p, dim3(tiles, 1), st);
+  else                  launch_cfg<MODE, KC, 1, 1, 1, 4>(p, dim3(tiles, 1), st);
+}
+
+}  // namespace
+
+extern "C" {
+
+// reduction-channel padding (16 per MFMA k-step; the kernel walks chunks of 32 or 64) and output-channel padding of a pack
+int odvae_conv_bf16_reduce_pad(int c) { return c % 64 == 0 ? c : pad_to(c, 32); }
+int odvae_conv_bf16_out_pad(int c) { return c > 64 ? pad_to(c, 128) : (c > 32 ? 64 : 32); }
+size_t odvae_conv_bf16_pack_elems(int reduce_c, int out_c, int taps) {
+  return (size_t)taps * odvae_conv_bf16_reduce_pad(reduce_c) * odvae_conv_bf16_out_pad(out_c);
+}
+
+// w: OIHW f32 [Cout][Cin][k][k], taps = k*k in {1, 9}.  fwd_pack / dgrad_pack: bf16, odvae_conv_bf16_pack_elems(Cin, Cout, taps) /
+// (Cout, Cin, taps) elements; either may be NULL.
+int odvae_conv_pack_bf16(const float* w, int Cout, int Cin, int taps, void* fwd_pack, void* dgrad_pack, void* stream) {
+  ODVAE_CHECK_ARG(w && Cout > 0 && Cin > 0 && (taps == 1 || taps == 9), "conv_pack_bf16: bad arguments");
+  const int64_t total = (fwd_pack ? (int64_t)odvae_conv_bf16_pack_elems(Cin, Cout, taps) : 0) +
+                        (dgrad_pack ? (int64_t)odvae_conv_bf16_pack_elems(Cout, Cin, taps) : 0);
+  if (total == 0) return ODVAE_OK;
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
+  hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, taps,
+                     static_cast<bf16_t*>(fwd_pack), odvae_conv_bf16_reduce_pad(Cin), odvae_conv_bf16_out_pad(Cout),
+                     static_cast<bf16_t*>(dgrad_pack), odvae_conv_bf16_reduce_pad(Cout), odvae_conv_bf16_out_pad(Cin));
+  ODVAE_LAUNCH_CHECK("conv_pack_bf16");
+  return ODVAE_OK;
+}
+
+// y = conv(x) (+ bias) (+ residual).  x bf16 NHWC [N][Hi][Wi][Cin] (Cin % 8 == 0), pack from odvae_conv_pack_bf16 with
+// (reduce = Cin, out = Cout), bias f32 [Cout] or NULL, residual bf16 [N][Ho][Wo][Cout] or NULL, y bf16 (out_f32 = 0; needs
+// Cout % 4 == 0) or f32 (out_f32 = 1, any Cout).  mode 0..3 as in odvae_conv3x3_f32; mode 4 = 1x1 on [N][Hi][Wi] = [1][M/16][16].
+int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, const void* pack, int Cout, const float* bias,
+                    const void* residual, void* y, int Ho, int Wo, int out_f32, void* stream) {
+  ODVAE_CHECK_ARG(mode >= 0 && mode <= 4, "conv_bf16: mode %d", mode);
+  ODVAE_CHECK_ARG(x && pack && y && N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_bf16: null or empty operand");
+  ODVAE_CHECK_ARG(Cin % 8 == 0, "conv_bf16: Cin = %d must be a multiple of 8 (16-byte channel vectors)", Cin);
+  ODVAE_CHECK_ARG(out_f32 || Cout % 4 == 0, "conv_bf16: bf16 output needs Cout %% 4 == 0, got %d", Cout);
+  ODVAE_CHECK_ARG(!residual || (!out_f32 && Cout % 4 == 0), "conv_bf16: residual needs a bf16 output with Cout %% 4 == 0");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)pack & 15) == 0 && ((uintptr_t)y & 7) == 0 && ((uintptr_t)residual & 7) == 0,
+                  "conv_bf16: misaligned operand");
+  int eh, ew;
+  if (mode == 0 || mode == 4) { eh = Hi; ew = Wi; }
+  else if (mode == 1) { eh = (Hi - 2) / 2 + 1; ew = (Wi - 2) / 2 + 1; }   // (H + 1 - 3)/2 + 1 with the (0,1,0,1) pad
+  else { eh = 2 * Hi; ew = 2 * Wi; }
+  ODVAE_CHECK_ARG(Ho == eh && Wo == ew, "conv_bf16(mode %d): output %dx%d does not match input %dx%d (expected %dx%d)", mode, Ho, Wo, Hi, Wi, eh, ew);
+  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 2 < 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * 4 < 0x7FFFFFF0ll,
+                  "conv_bf16: one image exceeds the 2 GiB buffer-descriptor range");
+  ConvB p;
+  p.x = static_cast<const bf16_t*>(x); p.wpk = static_cast<const bf16_t*>(pack); p.bias = bias;
+  p.residual = static_cast<const bf16_t*>(residual); p.y = y;
+  p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+  p.CinP = odvae_conv_bf16_reduce_pad(Cin); p.CoutP = odvae_conv_bf16_out_pad(Cout);
+  p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, TH); p.out_f32 = out_f32;
+  ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool k64 = p.CinP % 64 == 0;
+  switch (mode) {
+    case 0: if (k64) launch_by_cout<0, 64>(p, st); else launch_by_cout<0, 32>(p, st); break;
+    case 1: launch_by_cout<1, 16>(p, st); break;   // 17x33 halo pixels: KC = 16 keeps the two stages under 64 KB
+    case 2: launch_by_cout<2, 32>(p, st); break;
+    case 3: launch_by_cout<3, 32>(p, st); break;
+    default: if (k64) launch_by_cout<4, 64>(p, st); else launch_by_cout<4, 32>(p, st); break;
+  }
+  ODVAE_LAUNCH_CHECK("conv_bf16");
+  return ODVAE_OK;
+}
+
+}  // extern "C"

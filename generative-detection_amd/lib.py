@@ -71,6 +71,25 @@ PROTOTYPES = {
     "odvae_maxpool2x2_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "odvae_lpips_distance_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
     "odvae_lpips_distance_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    # bf16 mixed-precision path
+    "odvae_conv_bf16_reduce_pad": (_I, [_I]),
+    "odvae_conv_bf16_out_pad": (_I, [_I]),
+    "odvae_conv_bf16_pack_elems": (_Z, [_I, _I, _I]),
+    "odvae_conv_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "odvae_conv_bf16": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "odvae_conv_wgrad_bf16_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "odvae_conv_wgrad_bf16": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "odvae_flash_attn_supported": (_I, [_I, _I, _I]),
+    "odvae_flash_attn_fwd_bf16": (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
+    "odvae_flash_attn_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "odvae_groupnorm_bf16_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "odvae_groupnorm_fwd_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
+    "odvae_groupnorm_bwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "odvae_cast_pad_bf16": (_I, [_P, _L, _I, _I, _P, _P]),
+    "odvae_cast_f32_from_bf16": (_I, [_P, _L, _P, _P]),
+    "odvae_upsample2x_bwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "odvae_colsum_bf16_workspace_bytes": (_Z, [_L, _I]),
+    "odvae_colsum_bf16": (_I, [_P, _L, _I, _P, _P, _Z, _P]),
     "odvae_patch_table_ints": (_I, [_I]),
     "odvae_patch_crop_resize_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
@@ -130,13 +149,13 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def require_device(*tensors):
+def require_device(*tensors, dtypes=(torch.float32,)):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise HipLibraryError(
                 "OD-VAE HIP op called with a %s tensor: the hot path runs only on a HIP device (no CPU fallback)" % t.device)
-        if t is not None and t.dtype != torch.float32:
-            raise HipLibraryError("OD-VAE HIP op needs float32 tensors, got %s" % t.dtype)
+        if t is not None and t.dtype not in dtypes:
+            raise HipLibraryError("OD-VAE HIP op needs %s tensors, got %s" % (" / ".join(str(d) for d in dtypes), t.dtype))
 
 
 class _Workspace:

@@ -36,8 +36,8 @@ class Conv3x3(nn.Conv2d):
         super().__init__(cin, cout, kernel_size=3, stride=stride, padding=pad)
         self.mode = mode
 
-    def forward(self, x, residual=None):
-        return ops.conv3x3(x, self.weight, self.bias, residual, self.mode)
+    def forward(self, x, residual=None, out_f32=False):
+        return ops.conv3x3(x, self.weight, self.bias, residual, self.mode, out_f32=out_f32)
 
 
 class Conv1x1(nn.Conv2d):
@@ -140,6 +140,8 @@ class Encoder(nn.Module):
         self.num_resolutions = len(ch_mult)
         self.num_res_blocks = num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
+        # torch.float32, or torch.bfloat16 = the trainer's `precision: bf16` (configs[4]): bf16 activations, f32 master weights
+        self.compute_dtype = torch.float32
         self.conv_in = Conv3x3(in_channels, ch)
         curr_res = resolution
         widths = [ch * m for m in (1,) + tuple(ch_mult)]
@@ -168,6 +170,8 @@ class Encoder(nn.Module):
         self.conv_out = Conv3x3(block_in, 2 * z_channels if double_z else z_channels)
 
     def forward(self, x):
+        if self.compute_dtype == torch.bfloat16:
+            x = ops.to_bf16(x, pad_channels_to=8)   # 3-channel image -> 16-byte channel vectors (the extra channels are zero)
         h = self.conv_in(x)
         for level, stage in enumerate(self.down):
             for i, block in enumerate(stage.block):
@@ -177,7 +181,7 @@ class Encoder(nn.Module):
             if level != self.num_resolutions - 1:
                 h = stage.downsample(h)
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
-        return self.conv_out(self.norm_out(h, swish=True))
+        return self.conv_out(self.norm_out(h, swish=True), out_f32=True)   # the moments leave the encoder in f32
 
 
 class Decoder(nn.Module):
@@ -188,6 +192,7 @@ class Decoder(nn.Module):
         # activation_checkpoint (not an upstream key; upstream swallows unknown keys through **ignorekwargs): keep only
         # the input of each ResnetBlock(+AttnBlock) unit and recompute its interior in backward (BASELINE.json config 5).
         self.activation_checkpoint = bool(activation_checkpoint)
+        self.compute_dtype = torch.float32   # see Encoder
         if use_linear_attn:
             attn_type = "linear"
         if tanh_out:
@@ -226,6 +231,8 @@ class Decoder(nn.Module):
 
     def forward(self, z):
         self.last_z_shape = z.shape
+        if self.compute_dtype == torch.bfloat16:
+            z = ops.to_bf16(z)
         h = self.conv_in(z)
         recompute = self.activation_checkpoint and torch.is_grad_enabled() and h.requires_grad
         run = (lambda f, t: torch.utils.checkpoint.checkpoint(f, t, use_reentrant=False)) if recompute else (lambda f, t: f(t))
@@ -239,4 +246,4 @@ class Decoder(nn.Module):
                 h = stage.upsample(h)
         if self.give_pre_end:
             return h
-        return self.conv_out(self.norm_out(h, swish=True))
+        return self.conv_out(self.norm_out(h, swish=True), out_f32=True)   # the reconstruction (and the losses on it) stay f32

@@ -20,9 +20,12 @@ def _L():
     return _lib.load()
 
 
-def _cl(t):
+BF16 = torch.bfloat16
+
+
+def _cl(t, dtype=torch.float32):
     """NHWC-in-memory view of a logical NCHW tensor (copy only if the caller handed us another layout)."""
-    _lib.require_device(t)
+    _lib.require_device(t, dtypes=(dtype,))
     if t.dim() != 4:
         raise ValueError("expected a 4-d NCHW tensor, got shape %s" % (tuple(t.shape),))
     n, c, h, w = t.shape
@@ -35,8 +38,8 @@ def _cl(t):
     return out
 
 
-def _new_cl(n, c, h, w, like):
-    t = torch.empty((n, h, w, c), dtype=torch.float32, device=like.device)
+def _new_cl(n, c, h, w, like, dtype=torch.float32):
+    t = torch.empty((n, h, w, c), dtype=dtype, device=like.device)
     return t.permute(0, 3, 1, 2)
 
 
@@ -138,6 +141,12 @@ def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False, up=False):
     w = weight.detach().contiguous()
     _lib.require_device(w)
     cout, cin = w.shape[0], w.shape[1]
+    if up == "bf16":   # bf16 MFMA-fragment packs of a 3x3 or 1x1 conv (conv_bf16.hip); master weights stay f32
+        taps = w.shape[2] * w.shape[3]
+        fwd = torch.empty(L.odvae_conv_bf16_pack_elems(cin, cout, taps), dtype=BF16, device=w.device) if want_fwd else None
+        dgr = torch.empty(L.odvae_conv_bf16_pack_elems(cout, cin, taps), dtype=BF16, device=w.device) if want_dgrad else None
+        _lib.check(L.odvae_conv_pack_bf16(w.data_ptr(), cout, cin, taps, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv_pack_bf16")
+        return fwd, dgr
     floats = (L.odvae_conv3x3_wino_pack_floats if up == "wino" else
               L.odvae_conv3x3_up_pack_floats if up else L.odvae_conv3x3_pack_floats)
     fwd = dgr = None
@@ -298,7 +307,13 @@ class _Conv3x3(Function):
         return dx, dw, db, dres, None, None
 
 
-def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False):
+def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=False):
+    """bf16 activations take the mixed-precision kernels (conv_bf16.hip); out_f32 makes that path hand back f32 (the f32 ends of
+    the network: encoder.conv_out -> moments, decoder.conv_out -> reconstruction)."""
+    if x.dtype == BF16:
+        if relu:
+            raise NotImplementedError("fused ReLU is only on the f32 path (the LPIPS-style VGG stack stays f32)")
+        return _ConvB.apply(x, weight, bias, residual, mode, bool(out_f32))
     return _Conv3x3.apply(x, weight, bias, residual, mode, relu)
 
 
@@ -368,6 +383,8 @@ class _Conv1x1(Function):
 
 
 def conv1x1(x, weight, bias=None, residual=None):
+    if x.dtype == BF16:
+        return _ConvB.apply(x, weight, bias, residual, 4, False)
     return _Conv1x1.apply(x, weight, bias, residual)
 
 
@@ -440,6 +457,8 @@ class _Attention(Function):
 
 
 def attention_qkv(qkv):
+    if qkv.dtype == BF16:
+        return _FlashAttention.apply(qkv)
     return _Attention.apply(qkv)
 
 
@@ -498,6 +517,8 @@ class _GroupNorm(Function):
 
 
 def group_norm(x, gamma, beta, groups=32, eps=1e-6, swish=False):
+    if x.dtype == BF16:
+        return _GroupNormB.apply(x, gamma, beta, groups, eps, swish)
     return _GroupNorm.apply(x, gamma, beta, groups, eps, swish)
 
 
@@ -505,6 +526,8 @@ def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     """(GroupNorm(x), x): the second output is x itself, to be used by the block's skip connection (`x + h`).  Its
     gradient returns into this node and is summed into dx inside the GroupNorm backward pass (one pass instead of
     autograd's separate 3-pass add)."""
+    if x.dtype == BF16:
+        return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, True)
     return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True)
 
 
@@ -927,3 +950,250 @@ class _LpipsDistance(Function):
 
 def lpips_layer_distance(f0, f1, lin_w):
     return _LpipsDistance.apply(f0, f1, lin_w)
+
+
+# ------------------------------------------------------------------------------------------------------
+# bf16 mixed-precision path (BASELINE.json configs[4]): bf16 activations in HBM, f32 master weights / gradients / statistics
+# ------------------------------------------------------------------------------------------------------
+_I31 = 0x7FFFFFF0
+
+
+def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32):
+    """One odvae_conv_bf16 call.  mode 4 (1x1) flattens the pixels to [1][M/wi][wi]; images are processed in groups small enough
+    for the 2 GiB buffer descriptors."""
+    L = _L()
+    n, cx, hi, wi = x.shape
+    if mode in (0, 4):
+        ho, wo = hi, wi
+    elif mode == 1:
+        ho, wo = hi // 2, wi // 2
+    else:
+        ho, wo = 2 * hi, 2 * wi
+    y = _new_cl(n, cout, ho, wo, x, dtype=torch.float32 if out_f32 else BF16)
+    esz = 4 if out_f32 else 2
+    if mode != 4:
+        tag = KERNEL_EVENTS.begin()
+        _lib.check(L.odvae_conv_bf16(mode, x.data_ptr(), n, hi, wi, cx, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                                     y.data_ptr(), ho, wo, int(out_f32), _lib.stream_ptr()), "conv_bf16(mode=%d)" % mode)
+        KERNEL_EVENTS.end("conv_bf16", 2.0 * 9 * cx * cout * n * ho * wo, tag,
+                          2.0 * n * hi * wi * cx + esz * n * ho * wo * cout * (2 if residual is not None else 1) + 2.0 * 9 * cx * cout)
+        return y
+    per = hi * wi
+    grp = max(1, min(n, _I31 // max(per * cx * 2, per * cout * esz)))
+    for a in range(0, n, grp):
+        b = min(n, a + grp)
+        m = (b - a) * per
+        w16 = next(d for d in (16, 8, 4, 2, 1) if m % d == 0)
+        tag = KERNEL_EVENTS.begin(secondary=True)
+        _lib.check(L.odvae_conv_bf16(4, x.data_ptr() + a * per * cx * 2, 1, m // w16, w16, cx, pack.data_ptr(), cout, _lib.ptr(bias),
+                                     None if residual is None else residual.data_ptr() + a * per * cout * 2,
+                                     y.data_ptr() + a * per * cout * esz, m // w16, w16, int(out_f32), _lib.stream_ptr()), "conv_bf16(1x1)")
+        KERNEL_EVENTS.end("conv1x1_bf16", 2.0 * cx * cout * m, tag, 2.0 * m * cx + esz * m * cout)
+    return y
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+class _ConvB(Function):
+    """3x3 (modes 0 / 1 / 2) or 1x1 (mode 4) convolution on bf16 NHWC activations; weight / bias are the f32 master parameters
+    (OIHW), their gradients come back in f32.  x may carry zero channels beyond weight.shape[1] (the 3-channel image padded to 8)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, mode, out_f32):
+        L = _L()
+        x = _cl(x, BF16)
+        res = _cl(residual, BF16) if residual is not None else None
+        cout, cin = weight.shape[0], weight.shape[1]
+        if x.shape[1] != cin and L.odvae_conv_bf16_reduce_pad(x.shape[1]) != L.odvae_conv_bf16_reduce_pad(cin):
+            raise ValueError("conv_bf16: input has %d channels, weight expects %d" % (x.shape[1], cin))
+        fwd_pack, dpack = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), "bf16")
+        b = bias.detach().contiguous() if bias is not None else None
+        y = _conv_b_raw(mode, x, fwd_pack, cout, b, res, out_f32)
+        ctx.mode, ctx.has_bias, ctx.has_res, ctx.dpack = mode, bias is not None, residual is not None, dpack
+        ctx.wshape = tuple(weight.shape)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        (x,) = ctx.saved_tensors
+        mode = ctx.mode
+        cout, cin = ctx.wshape[0], ctx.wshape[1]
+        n, cx, hi, wi = x.shape
+        _, _, ho, wo = dy.shape
+        dyb, cp = dy, cout
+        if dy.dtype != BF16:                 # f32 upstream gradient (reconstruction / moments): one cast (+ channel pad) pass
+            cp = _pad8(cout)
+            dyb = cast_pad_bf16(_cl(dy), cp)
+        else:
+            dyb = _cl(dy, BF16)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if cx != cin:
+                raise NotImplementedError("data gradient through a channel-padded input")
+            if mode == 0:
+                dx = _conv_b_raw(0, dyb, ctx.dpack, cin, None, None, False)
+            elif mode == 1:
+                dx = _conv_b_raw(3, dyb, ctx.dpack, cin, None, None, False)
+            elif mode == 4:
+                dx = _conv_b_raw(4, dyb, ctx.dpack, cin, None, None, False)
+            else:                            # Upsample: gradient w.r.t. the upsampled image, then its 2x2 sum-pool
+                du = _conv_b_raw(0, dyb, ctx.dpack, cin, None, None, False)
+                dx = _new_cl(n, cin, hi, wi, x, dtype=BF16)
+                _lib.check(L.odvae_upsample2x_bwd_bf16(du.data_ptr(), dx.data_ptr(), n, hi, wi, cin, _lib.stream_ptr()), "upsample2x_bwd_bf16")
+        if ctx.needs_input_grad[1]:
+            taps = ctx.wshape[2] * ctx.wshape[3]
+            dwf = torch.empty((cp, cx) + tuple(ctx.wshape[2:]), dtype=torch.float32, device=x.device)
+            if mode == 4:
+                per = hi * wi
+                grp = max(1, min(n, _I31 // (per * max(cx, cp) * 2)))
+                if grp < n:
+                    raise NotImplementedError("1x1 weight gradient over more than 2 GiB of activations")
+                m = n * per
+                w16 = next(d for d in (16, 8, 4, 2, 1) if m % d == 0)
+                geo = (1, m // w16, w16, cx, m // w16, w16, cp)
+            else:
+                geo = (n, hi, wi, cx, ho, wo, cp)
+            need = L.odvae_conv_wgrad_bf16_workspace_bytes(mode, geo[0], geo[4], geo[5], cx, cp)
+            wp, wn = _ws(need, x)
+            tag = KERNEL_EVENTS.begin(secondary=True)
+            _lib.check(L.odvae_conv_wgrad_bf16(mode, x.data_ptr(), dyb.data_ptr(), *geo, dwf.data_ptr(), wp, wn, _lib.stream_ptr()),
+                       "conv_wgrad_bf16(mode=%d)" % mode)
+            KERNEL_EVENTS.end("conv_wgrad_bf16", 2.0 * taps * cx * cp * n * ho * wo, tag, 2.0 * n * (hi * wi * cx + ho * wo * cp))
+            dw = dwf if (cp == cout and cx == cin) else dwf[:cout, :cin].contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if dy.dtype != BF16:
+                db = _colsum(_cl(dy), n * ho * wo, cout)
+            else:
+                db = torch.empty(cout, dtype=torch.float32, device=x.device)
+                rows = n * ho * wo
+                wp, wn = _ws(L.odvae_colsum_bf16_workspace_bytes(rows, cout), x)
+                _lib.check(L.odvae_colsum_bf16(dyb.data_ptr(), rows, cout, db.data_ptr(), wp, wn, _lib.stream_ptr()), "colsum_bf16")
+        dres = dyb if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres, None, None
+
+
+def cast_pad_bf16(x, cp=None):
+    """bf16 NHWC copy of an f32 NHWC tensor, channels zero-padded to cp (raw, no autograd)."""
+    L = _L()
+    n, c, h, w = x.shape
+    cp = c if cp is None else cp
+    y = _new_cl(n, cp, h, w, x, dtype=BF16)
+    _lib.check(L.odvae_cast_pad_bf16(x.data_ptr(), n * h * w, c, cp, y.data_ptr(), _lib.stream_ptr()), "cast_pad_bf16")
+    return y
+
+
+class _ToBF16(Function):
+    """f32 -> bf16 hand-off into the mixed-precision network (optionally zero-padding the channels to a multiple of 8); the
+    gradient comes back as f32 on the original channels."""
+
+    @staticmethod
+    def forward(ctx, x, cp):
+        x = _cl(x)
+        ctx.c = x.shape[1]
+        return cast_pad_bf16(x, cp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        dy = _cl(dy, BF16)
+        n, cp, h, w = dy.shape
+        dx = _new_cl(n, cp, h, w, dy)
+        _lib.check(L.odvae_cast_f32_from_bf16(dy.data_ptr(), dy.numel(), dx.data_ptr(), _lib.stream_ptr()), "cast_f32_from_bf16")
+        return (dx if cp == ctx.c else dx[:, :ctx.c]), None
+
+
+def to_bf16(x, pad_channels_to=None):
+    if x.dtype == BF16:
+        return x
+    c = x.shape[1]
+    cp = c if pad_channels_to is None else max(c, (c + pad_channels_to - 1) // pad_channels_to * pad_channels_to)
+    return _ToBF16.apply(x, cp)
+
+
+class _GroupNormB(Function):
+    """GroupNorm(+swish) on bf16 activations: statistics and arithmetic in f32, one rounding on the way out."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False):
+        L = _L()
+        x = _cl(x, BF16)
+        n, c, h, w = x.shape
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = _new_cl(n, c, h, w, x, dtype=BF16)
+        mean = torch.empty(n, groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(n, groups, dtype=torch.float32, device=x.device)
+        wp, wn = _ws(L.odvae_groupnorm_bf16_workspace_bytes(n, h * w, c, groups), x)
+        tag = KERNEL_EVENTS.begin(secondary=True)
+        _lib.check(L.odvae_groupnorm_fwd_bf16(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps), int(swish),
+                                              y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn, _lib.stream_ptr()), "groupnorm_fwd_bf16")
+        KERNEL_EVENTS.end("groupnorm", 0.0, tag, 2.0 * 2 * n * h * w * c, issued=0.0)
+        ctx.groups, ctx.swish = groups, int(swish)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.set_materialize_grads(False)
+        if with_skip:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        L = _L()
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None, None, None, None
+        dy = _cl(dy, BF16)
+        if dskip is not None:
+            dskip = _cl(dskip, BF16)
+        n, c, h, w = x.shape
+        dx = _new_cl(n, c, h, w, x, dtype=BF16)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        wp, wn = _ws(L.odvae_groupnorm_bf16_workspace_bytes(n, h * w, c, ctx.groups), x)
+        tag = KERNEL_EVENTS.begin(secondary=True)
+        _lib.check(L.odvae_groupnorm_bwd_bf16(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(), b.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                              _lib.ptr(dskip), wp, wn, _lib.stream_ptr()), "groupnorm_bwd_bf16")
+        KERNEL_EVENTS.end("groupnorm", 0.0, tag, 2.0 * (3 + (dskip is not None)) * n * h * w * c, issued=0.0)
+        return dx, dg, db, None, None, None, None
+
+
+class _FlashAttention(Function):
+    """softmax(q k^T C^-1/2) v from the packed bf16 projection [N, 3C, H, W]; the T x T scores stay on the CU (flash_attn_bf16.hip);
+    only o and the per-row log-sum-exp are kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        L = _L()
+        qkv = _cl(qkv, BF16)
+        n, c3, h, w = qkv.shape
+        c, t = c3 // 3, h * w
+        if not L.odvae_flash_attn_supported(n, t, c):
+            raise _lib.HipLibraryError("flash attention: unsupported shape N=%d T=%d C=%d" % (n, t, c))
+        o = _new_cl(n, c, h, w, qkv, dtype=BF16)
+        lse = torch.empty(n, t, dtype=torch.float32, device=qkv.device)
+        tag = KERNEL_EVENTS.begin(secondary=True)
+        _lib.check(L.odvae_flash_attn_fwd_bf16(qkv.data_ptr(), n, t, c, float(c) ** -0.5, o.data_ptr(), lse.data_ptr(), _lib.stream_ptr()),
+                   "flash_attn_fwd")
+        KERNEL_EVENTS.end("flash_attn", 4.0 * t * t * c * n, tag, 2.0 * n * t * 4 * c)
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        L = _L()
+        qkv, o, lse = ctx.saved_tensors
+        do = _cl(do, BF16)
+        n, c3, h, w = qkv.shape
+        c, t = c3 // 3, h * w
+        dqkv = _new_cl(n, c3, h, w, qkv, dtype=BF16)
+        delta = torch.empty(n * t, dtype=torch.float32, device=qkv.device)
+        tag = KERNEL_EVENTS.begin(secondary=True)
+        _lib.check(L.odvae_flash_attn_bwd_bf16(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), n, t, c, float(c) ** -0.5,
+                                               dqkv.data_ptr(), delta.data_ptr(), _lib.stream_ptr()), "flash_attn_bwd")
+        # algorithmic: the five products of the backward (S, dP, dV, dK, dQ); issued: seven (S and dP are formed in both kernels)
+        KERNEL_EVENTS.end("flash_attn", 10.0 * t * t * c * n, tag, 2.0 * n * t * 8 * c, issued=14.0 * t * t * c * n)
+        return dqkv

@@ -55,7 +55,7 @@ def main(argv=None):
     model = instantiate_from_config(config.model)
     configure_learning_rate(config, model, trainer_cfg, scale_lr=opt.scale_lr, ngpu=1)
     model = model.to(opt.device).train()
-    trainer = Trainer(model, gradient_clip_val=trainer_cfg.get("gradient_clip_val", None))
+    trainer = Trainer(model, gradient_clip_val=trainer_cfg.get("gradient_clip_val", None), precision=trainer_cfg.get("precision", None))
     bs = config.data.params.batch_size
     for step in range(opt.steps):
         batch = synthetic.make_batch(bs, opt.height, seed=opt.seed + step)

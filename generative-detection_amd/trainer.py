@@ -19,10 +19,12 @@ class _TrainerHandle:
 
 
 class Trainer:
-    def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=32.0):
+    def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=32.0, precision=None):
         """optimizer_indices: which of the model's optimizers run each batch; (0,) is the "rec+KL only" benchmark
         configuration (discriminator off, optimizer 1 skipped -- SURVEY.md 8(d))."""
         self.model = model
+        if precision is not None:   # lightning.trainer.precision of the yaml (:139): 32 or "bf16"
+            model.set_precision(precision)
         self.clip = gradient_clip_val
         self.optimizer_indices = tuple(optimizer_indices)
         opts, _ = model.configure_optimizers()

@@ -199,6 +199,49 @@ int odvae_patch_table_ints(int S);
 int odvae_patch_crop_resize_u8(const void* d_images, const void* d_geom, const void* d_mask_rect, const void* d_tables,
                                int n_slots, int B, int S, void* patch, void* mask, void* stream);
 
+/* ==== bf16 mixed-precision path (BASELINE.json configs[4]; reference knobs: configs/autoencoder/pose/autoencoder_kl_16x16x16.yaml:139
+ * `precision`, train.py:521).  Activations bf16 NHWC in HBM, master weights / weight gradients / statistics f32, accumulation f32
+ * on v_mfma_f32_32x32x16_bf16.  Every `void*` activation pointer below is bf16 unless the comment says otherwise. ================ */
+
+/* ---- conv_bf16.hip: 3x3 / 1x1 convolutions ([UPSTREAM] ldm model.py via feat_encoder.py:4, feat_decoder.py:4) ---------------- */
+int odvae_conv_bf16_reduce_pad(int c);
+int odvae_conv_bf16_out_pad(int c);
+size_t odvae_conv_bf16_pack_elems(int reduce_c, int out_c, int taps);
+/* OIHW f32 weights [Cout][Cin][k][k] (taps = k*k in {1, 9}) -> bf16 MFMA-fragment packs: fwd (reduce Cin, rows Cout) and dgrad
+   (reduce Cout, rows Cin, taps flipped); either may be NULL */
+int odvae_conv_pack_bf16(const float* w, int Cout, int Cin, int taps, void* fwd_pack, void* dgrad_pack, void* stream);
+/* mode 0 stride 1 pad 1 | 1 Downsample pad(0,1,0,1)+stride 2 | 2 nearest-2x + stride 1 | 3 data gradient of mode 1 | 4 = 1x1 with the
+   pixels flattened to [N][Hi][Wi] = [1][M/16][16].  x [N][Hi][Wi][Cin] (Cin % 8 == 0), bias f32 or NULL, residual bf16
+   [N][Ho][Wo][Cout] or NULL, y bf16 (out_f32 = 0, Cout % 4 == 0) or f32 (out_f32 = 1) */
+int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, const void* pack, int Cout, const float* bias,
+                    const void* residual, void* y, int Ho, int Wo, int out_f32, void* stream);
+/* ---- conv_wgrad_bf16.hip: weight gradient, dw f32 OIHW, modes 0 / 1 / 2 / 4 as above; deterministic ---------------------------- */
+size_t odvae_conv_wgrad_bf16_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout);
+int odvae_conv_wgrad_bf16(int mode, const void* x, const void* dy, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout,
+                          float* dw, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- flash_attn_bf16.hip: fused single-head attention ([UPSTREAM] AttnBlock.forward), scores never in HBM --------------------- */
+int odvae_flash_attn_supported(int N, int T, int C);
+/* qkv [N][T][3C] (q | k | v) -> o [N][T][C], lse2 f32 [N][T] = log2 sum_j exp(score_ij * scale) */
+int odvae_flash_attn_fwd_bf16(const void* qkv, int N, int T, int C, float scale, void* o, float* lse2, void* stream);
+/* dqkv [N][T][3C] from d_o, o, lse2; delta_ws f32 [N*T] scratch */
+int odvae_flash_attn_bwd_bf16(const void* qkv, const void* o, const void* d_o, const float* lse2, int N, int T, int C, float scale,
+                              void* dqkv, float* delta_ws, void* stream);
+/* ---- bf16_ops.hip: GroupNorm(32, eps 1e-6) + swish with bf16 activations / f32 statistics, dtype hand-offs ---------------------- */
+size_t odvae_groupnorm_bf16_workspace_bytes(int N, int HW, int C, int G);
+int odvae_groupnorm_fwd_bf16(const void* x, int N, int HW, int C, int G, const float* gamma, const float* beta, float eps, int swish,
+                             void* y, float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+int odvae_groupnorm_bwd_bf16(const void* x, const void* dy, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, int swish, void* dx, float* dgamma, float* dbeta, const void* dx_add,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* y bf16 [rows][CP] = x f32 [rows][C], channels C..CP-1 zero (CP % 8 == 0) */
+int odvae_cast_pad_bf16(const float* x, int64_t rows, int C, int CP, void* y, void* stream);
+int odvae_cast_f32_from_bf16(const void* x, int64_t n, float* y, void* stream);
+/* dx [N][H][W][C] = 2x2 sum-pool of du [N][2H][2W][C]: data gradient of F.interpolate(scale 2, nearest) */
+int odvae_upsample2x_bwd_bf16(const void* du, void* dx, int N, int H, int W, int C, void* stream);
+size_t odvae_colsum_bf16_workspace_bytes(int64_t rows, int C);
+/* out f32 [C] = column sums of x bf16 [rows][C] (bias gradients) */
+int odvae_colsum_bf16(const void* x, int64_t rows, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
