@@ -204,6 +204,8 @@ def main():
     model.train()
     if args.ckpt_decoder:
         model.decoder.activation_checkpoint = True
+    if args.bf16:
+        model.set_precision("bf16")   # bf16 activations on the bf16 MFMA kernels + fused attention; f32 master weights
     # steady state: past the very first optimizer step, whose total holds the pose terms only (`global_step >
     # encoder_pretrain_steps`, contperceptual.py:307) and would skip the decoder's backward pass -- every timed step does the
     # full forward + backward + optimizer work even with --warmup 0
@@ -238,7 +240,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    roof = ops.KERNEL_EVENTS.summary("conv3x3_128x128") if not args.no_kernel_events else None
+    dom_key = "conv_bf16" if args.bf16 else "conv3x3_128x128"
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS if args.bf16 else PEAK_F32_MFMA_TFLOPS
+    roof = ops.KERNEL_EVENTS.summary(dom_key) if not args.no_kernel_events else None
     ops.KERNEL_EVENTS.issued_timed = ops.KERNEL_EVENTS.issued
     others, extra_ms = {}, None
     if roof is not None:   # ONE more step, outside the timed region, with the secondary kernel families bracketed as well
@@ -248,7 +252,8 @@ def main():
         step(args.warmup + args.steps)
         torch.cuda.synchronize()
         extra_ms = (time.perf_counter() - t1) * 1e3
-        others = {k: ops.KERNEL_EVENTS.summary(k) for k in ("conv3x3_wgrad_wino", "gemm_f32", "flash_attn", "groupnorm")}
+        others = {k: ops.KERNEL_EVENTS.summary(k) for k in ("conv3x3_wgrad_wino", "gemm_f32", "conv_wgrad_bf16", "conv1x1_bf16",
+                                                            "flash_attn", "groupnorm")}
     ops.KERNEL_EVENTS.disable()
 
     if rank == 0:
@@ -259,12 +264,13 @@ def main():
             "unit": "images/s",
             "n_gpus": world, "ranks_joined": ranks_joined, "backend": "rccl" if use_dist else "none", "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
                        % (args.res, args.res, args.batch,
                           ("PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
                            else "rec+KL only (discriminator off, optimizer 0)")
-                          + (", activation-checkpointed Decoder" if args.ckpt_decoder else "")),
+                          + (", activation-checkpointed Decoder" if args.ckpt_decoder else "")
+                          + (", bf16 mixed precision (bf16 activations, f32 master weights / accumulation)" if args.bf16 else ", fp32")),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         }
         if roof is not None:
@@ -276,13 +282,14 @@ def main():
                     break
             if tfile and not args.gan and args.batch == 32 and args.res == 256 and not args.ckpt_decoder and not args.bf16:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["hbm_bytes_per_launch"]
-            wino = ops.WINOGRAD
+            wino = ops.WINOGRAD and not args.bf16
             ratio = 16.0 / 36.0 if wino else 1.0      # Winograd F(2x2,3x3) issues 16 of the direct form's 36 multiply-adds
             issued = roof["tflops"] * ratio
-            out["roofline"] = {"bound": "mfma", "achieved": issued, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": issued / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            out["roofline"] = {"bound": "mfma", "achieved": issued, "peak": mfma_peak, "unit": "TFLOP/s",
+                               "frac": issued / mfma_peak, "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % tfile,
-                               "kernel": ("conv3x3_wino8_kernel (stride-1 3x3 conv fwd + dgrad, Winograd F(2x2,3x3), 32 tiles x 128 co per block)"
+                               "kernel": ("conv_bf16_kernel (3x3 conv fwd + dgrad, all modes, bf16 implicit GEMM, 128 px x 128 co per block)" if args.bf16
+                                          else "conv3x3_wino8_kernel (stride-1 3x3 conv fwd + dgrad, Winograd F(2x2,3x3), 32 tiles x 128 co per block)"
                                           if wino else "conv3x3_kernel_v2<MODE 0,KC 32,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)"),
                                "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
                                "issued_gflop_per_launch": roof["gflop_per_launch"] * ratio,
@@ -296,14 +303,16 @@ def main():
             # whole step: every multiply-add issued by the MFMA kernels of the timed steps (host-side count per launch)
             step_issued = ops.KERNEL_EVENTS.issued_timed / args.steps
             out["roofline_step"] = {"bound": "mfma", "issued_tflop_per_step": step_issued / 1e12,
-                                    "achieved": step_issued / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": step_issued / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                    "achieved": step_issued / (ms * 1e-3) / 1e12, "peak": mfma_peak, "unit": "TFLOP/s",
+                                    "frac": step_issued / (ms * 1e-3) / 1e12 / mfma_peak,
                                     "algorithmic_tflop_per_step": ALGORITHMIC_GFLOP_PER_IMAGE.get(args.res, 0.0) * args.batch / 1e3
                                     if not args.gan else None}
             # the next kernel families of the step, measured the same way (HIP events around every launch) on one extra step
             names = {"conv3x3_wgrad_wino": "conv3x3_wgrad_wino_kernel (weight gradient of the stride-1 3x3 convs in the Winograd domain)",
                      "gemm_f32": "gemm_f32_kernel (attention products incl. the fused softmax backward, 1x1 convs and their gradients)",
-                     "flash_attn": "flash_attn_{fwd,bwd} (fused attention: scores never leave the CU)",
+                     "flash_attn": "flash_fwd / flash_dq / flash_dkv kernels (fused attention: scores never leave the CU)",
+                     "conv_wgrad_bf16": "conv_wgrad_bf16_kernel (weight gradient of the 3x3 / 1x1 convs, transposed LDS reads)",
+                     "conv1x1_bf16": "conv_bf16_kernel<MODE 4> (1x1 convs: q/k/v/proj_out, nin_shortcut, and their data gradients)",
                      "groupnorm": "gn_* (GroupNorm(32, eps 1e-6) + swish, forward and backward incl. the folded skip gradient)"}
             out["roofline_others"] = []
             for key, r in others.items():
@@ -319,13 +328,13 @@ def main():
                               "note": "algorithmic bytes = x read + y written (forward), x, dy (, skip gradient) read + dx written (backward)"})
                 else:
                     k = 16.0 / 36.0 if key == "conv3x3_wgrad_wino" else 1.0
-                    e.update({"bound": "mfma", "achieved": r["tflops"] * k, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": r["tflops"] * k / PEAK_F32_MFMA_TFLOPS, "algorithmic_tflops": r["tflops"]})
+                    e.update({"bound": "mfma", "achieved": r["tflops"] * k, "peak": mfma_peak, "unit": "TFLOP/s",
+                              "frac": r["tflops"] * k / mfma_peak, "algorithmic_tflops": r["tflops"]})
                 out["roofline_others"].append(e)
         out["peak_device_memory_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
         print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.res, batch=2, steps=2)   # about 10 s of host work on 16 cores
+            out["cpu_baseline"] = cpu_baseline(args.res, batch=2 if args.res <= 256 else 1, steps=2 if args.res <= 256 else 1)   # 10-30 s of host work
             # BASELINE.json configs[0] beside it: the reference's own CPU-runnable case (64x64, B=2, 10 steps)
             out["cpu_baseline"]["config1"] = cpu_baseline(64, batch=2, steps=10)
         sys.stdout.flush()

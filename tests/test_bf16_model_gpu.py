@@ -1,0 +1,131 @@
+"""BASELINE.json configs[4] numerics: the training step in bf16 mixed precision (bf16 activations on the bf16 MFMA kernels, fused
+attention, f32 master weights / statistics / losses) against the CPU oracle.
+
+Two references on the same weights, batch and injected noise:
+  * the oracle in f32 (the ground truth), and
+  * the oracle under torch.autocast("cpu", dtype=torch.bfloat16) -- what the reference's own `precision: bf16` run computes
+    (configs/autoencoder/pose/autoencoder_kl_16x16x16.yaml:139, train.py:521).
+bf16 carries 8 significant bits, so a bf16 run differs from f32 by percents after ~60 layers; the stated tolerance per tensor is
+therefore "no further from the f32 oracle than TWICE the autocast oracle is, plus a floor":
+    latent moments, reconstruction:  err <= 2 * err_autocast + 2e-2   (relative to max|f32|)
+    scalar loss terms:               err <= 2 * err_autocast + 1e-2
+    parameter gradients (all of them, concatenated): cosine with the f32 gradient >= min(0.98, cos_autocast - 0.01);
+    per tensor, for tensors holding >= 1e-3 of the gradient energy: err <= 2 * err_autocast + 5e-2
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+YAML = os.path.join(os.path.dirname(__file__), "golden", "autoencoder_kl_16x16x16.yaml")
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().double(); b = b.detach().float().cpu().double()
+    return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
+
+
+def run_oracle(ref, batch, noise, autocast):
+    ref.zero_grad()
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            loss, log, aux = ref.training_step(batch, 0, noise)
+    else:
+        loss, log, aux = ref.training_step(batch, 0, noise)
+    loss.backward()
+    grads = {k: p.grad.detach().clone().float() for k, p in ref.named_parameters() if p.grad is not None}
+    return loss.detach().float(), {k: float(v) for k, v in log.items() if not torch.is_tensor(v) or v.numel() == 1}, aux, grads
+
+
+def flat(grads, keys):
+    return torch.cat([grads[k].flatten().double() for k in keys])
+
+
+@pytest.mark.parametrize("ch,height,latent_hw,ckpt", [(32, 64, 4, False), (32, 128, 8, True), (None, 256, 16, False)],
+                         ids=["narrow-64", "narrow-128-ckpt", "headline-256"])
+def test_bf16_step_is_as_close_to_f32_as_autocast(hip_lib, ch, height, latent_hw, ckpt):
+    from test_model_gpu import build_pair
+    from odvae_amd import synthetic
+    model, ref = build_pair(latent_hw=latent_hw, ch=ch, activation_checkpoint=ckpt)
+    model.set_precision("bf16")
+    model.train(); ref.train()
+    model._global_step = ref.global_step = 1
+    batch = synthetic.make_batch(2, height, seed=5)
+    noise = synthetic.make_noise(2, latent_hw, dropout_p=0.7, seed=6)
+    l32, log32, aux32, g32 = run_oracle(ref, batch, noise, False)
+    lac, logac, auxac, gac = run_oracle(ref, batch, noise, True)
+
+    model.injected_noise = noise
+    loss = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0, 0)
+    logs = model.logged_metrics
+    loss.backward()
+    with torch.no_grad():
+        dec_obj, dec_pose, post, _ = model.forward(model._rescale(batch["patch"].to("cuda:0")))
+    assert dec_obj.dtype == torch.float32 and post.parameters.dtype == torch.float32
+
+    report = []
+    def check(name, got, want, ac, floor):
+        e, eac = rel(got, want), rel(ac, want)
+        report.append("%s: hip %.3e autocast %.3e" % (name, e, eac))
+        assert e <= 2 * eac + floor, "%s: bf16 HIP path %.3e from the f32 oracle, autocast oracle %.3e (floor %.0e)" % (name, e, eac, floor)
+
+    check("moments", post.parameters, aux32["posterior"].parameters, auxac["posterior"].parameters, 2e-2)
+    check("reconstruction", dec_obj, aux32["dec_obj"], auxac["dec_obj"], 2e-2)
+    check("total loss", loss, l32, lac, 1e-2)
+    for key in ("kl_loss_obj", "nll_loss", "rec_loss", "pose_loss", "class_loss", "bbox_loss", "kl_loss_bbox"):
+        check(key, torch.as_tensor(float(logs["train/" + key])), torch.as_tensor(log32["train/" + key]),
+              torch.as_tensor(logac["train/" + key]), 1e-2)
+
+    params = dict(model.named_parameters())
+    keys = [k for k in g32 if params[k].grad is not None]
+    assert {k.split(".")[0] for k in keys} >= {"encoder", "decoder", "quant_conv_obj", "post_quant_conv"}
+    for k in keys:
+        assert params[k].grad.dtype == torch.float32 and torch.isfinite(params[k].grad).all(), k
+    ghip = {k: params[k].grad.detach().cpu().float() for k in keys}
+    v32, vhip, vac = flat(g32, keys), flat(ghip, keys), flat(gac, keys)
+    cos = lambda a, b: (a @ b / (a.norm() * b.norm())).item()
+    c_hip, c_ac = cos(vhip, v32), cos(vac, v32)
+    report.append("gradient cosine: hip %.5f autocast %.5f" % (c_hip, c_ac))
+    assert c_hip >= min(0.98, c_ac - 0.01), report[-1]
+    energy = v32.pow(2).sum().item()
+    for k in keys:
+        if g32[k].double().pow(2).sum().item() < 1e-3 * energy:
+            continue
+        e, eac = rel(ghip[k], g32[k]), rel(gac[k], g32[k])
+        assert e <= 2 * eac + 5e-2, "grad %s: hip %.3e autocast %.3e" % (k, e, eac)
+    print("\\n".join(report))
+
+
+def test_bf16_three_step_loss_curve(hip_lib):
+    """Three optimizer steps (clip + FusedAdam on f32 master weights) in bf16 track the f32 oracle's curve within 2 %."""
+    from test_model_gpu import build_pair
+    from odvae_amd import synthetic
+    from odvae_amd.trainer import Trainer
+    from oracle.autoencoder import train_batch
+    model, ref = build_pair()
+    model.train(); ref.train()
+    model._global_step = ref.global_step = 1
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), precision="bf16")
+    opts = ref.configure_optimizers()
+    for step in range(3):
+        batch = synthetic.make_batch(2, 64, seed=40 + step)
+        noise = synthetic.make_noise(2, 4, dropout_p=0.7, seed=50 + step)
+        model.injected_noise = noise
+        loss = trainer.training_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, step)[0]
+        loss_ref = train_batch(ref, opts, batch, {0: noise}, optimizer_indices=(0,), clip=1.0)[0][0]
+        assert rel(loss, loss_ref) < 2e-2, (step, loss.item(), loss_ref.item())
+    for p in model.encoder.parameters():
+        assert p.dtype == torch.float32      # master weights stay f32
+
+
+def test_precision_switch(hip_lib):
+    from test_model_gpu import build_pair
+    model, _ = build_pair()
+    assert model.encoder.compute_dtype == torch.float32
+    model.set_precision("bf16")
+    assert model.encoder.compute_dtype == torch.bfloat16 and model.decoder.compute_dtype == torch.bfloat16
+    model.set_precision(32)
+    assert model.decoder.compute_dtype == torch.float32
+    with pytest.raises(ValueError):
+        model.set_precision(16)
