@@ -15,6 +15,10 @@ CXX_SOURCES = ["runtime.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", CSRC]
 FLAGS += os.environ.get("ODVAE_EXTRA_HIPCC_FLAGS", "").split()   # diagnostic builds (-DODVAE_STAMPS, ...); use with force=True
+# Per-file code-generation switches (none in use).  Tried on flash_attn_bf16.hip: `-mllvm -amdgpu-mfma-vgpr-form=1` removes the
+# 256 v_accvgpr_read/write per 32 MFMAs that hipcc's default register split puts at the loop back-edge of the attention kernels
+# (592 vs 565 TFLOP/s forward), but the D >= 256 forward kernels then return wrong results (tests/test_bf16_gpu.py), so it stays off.
+PER_FILE_FLAGS = {}
 
 
 def _stale(target, deps):
@@ -26,9 +30,9 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bf16_common.h")]
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bf16_common.h"), os.path.abspath(__file__)]
     if _stale(obj, deps):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

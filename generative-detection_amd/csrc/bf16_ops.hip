@@ -308,15 +308,17 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     partial[(int64_t)blockIdx.x * C + c] = a;
   }
 }
+// one wave per channel: lanes stride over the blocks, fixed-order tree (deterministic)
 __global__ void colsum_finish_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
-  double a = 0.0;
-  for (int b = 0; b < blocks; ++b) a += (double)partial[(int64_t)b * C + c];
-  out[c] = (float)a;
+  float a = 0.f;
+  for (int b = lane; b < blocks; b += 64) a += partial[(int64_t)b * C + c];
+  a = wave_sum(a);
+  if (lane == 0) out[c] = a;
 }
 
-int colsum_blocks(int64_t rows) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div64(rows, 256))); }
+int colsum_blocks(int64_t rows) { return (int)std::min<int64_t>(512, std::max<int64_t>(1, ceil_div64(rows, 512))); }
 
 }  // namespace
 
@@ -425,7 +427,7 @@ int odvae_colsum_bf16(const void* x, int64_t rows, int C, float* out, void* work
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t*>(x), rows, C, (int)ceil_div64(rows, blocks), partial);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, partial, blocks, C, out);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, blocks, C, out);
   ODVAE_LAUNCH_CHECK("colsum_bf16");
   return ODVAE_OK;
 }

@@ -16,10 +16,11 @@
 // Block = 8x16 output pixels x BCO output channels, 4 waves; per KC input channels the halo patch [halo px][KC + 8] is
 // staged once (double-buffered, branch-free buffer loads with hardware zero fill), ONE barrier per chunk.
 #include "bf16_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int TH = 8, TW = 16;
+constexpr int TW = 16;   // tile width; the height TH is 8 (128 pixels) or 16 (256 pixels per block)
 
 struct ConvB {
   const bf16_t* x;         // [N][Hi][Wi][Cin]
@@ -31,22 +32,22 @@ struct ConvB {
   int tiles_x, tiles_y, out_f32;
 };
 
-template <int MODE> struct HaloB;
-template <> struct HaloB<0> { static constexpr int H = TH + 2, W = TW + 2, TAPS = 9; };
-template <> struct HaloB<1> { static constexpr int H = 2 * TH + 1, W = 2 * TW + 1, TAPS = 9; };
-template <> struct HaloB<2> { static constexpr int H = TH / 2 + 2, W = TW / 2 + 2, TAPS = 9; };
-template <> struct HaloB<3> { static constexpr int H = TH / 2 + 1, W = TW / 2 + 1, TAPS = 9; };
-template <> struct HaloB<4> { static constexpr int H = TH, W = TW, TAPS = 1; };
+template <int MODE, int TH> struct HaloB;
+template <int TH> struct HaloB<0, TH> { static constexpr int H = TH + 2, W = TW + 2, TAPS = 9; };
+template <int TH> struct HaloB<1, TH> { static constexpr int H = 2 * TH + 1, W = 2 * TW + 1, TAPS = 9; };
+template <int TH> struct HaloB<2, TH> { static constexpr int H = TH / 2 + 2, W = TW / 2 + 2, TAPS = 9; };
+template <int TH> struct HaloB<3, TH> { static constexpr int H = TH / 2 + 1, W = TW / 2 + 1, TAPS = 9; };
+template <int TH> struct HaloB<4, TH> { static constexpr int H = TH, W = TW, TAPS = 1; };
 
-template <int MODE>
+template <int MODE, int TH>
 __device__ __forceinline__ int halo_index_b(int r, int c, int kh, int kw, bool& ok) {
   ok = true;
-  if (MODE == 0) return (r + kh) * HaloB<0>::W + (c + kw);
-  if (MODE == 1) return (2 * r + kh) * HaloB<1>::W + (2 * c + kw);
-  if (MODE == 2) return ((r + kh + 1) >> 1) * HaloB<2>::W + ((c + kw + 1) >> 1);
+  if (MODE == 0) return (r + kh) * HaloB<0, TH>::W + (c + kw);
+  if (MODE == 1) return (2 * r + kh) * HaloB<1, TH>::W + (2 * c + kw);
+  if (MODE == 2) return ((r + kh + 1) >> 1) * HaloB<2, TH>::W + ((c + kw + 1) >> 1);
   if (MODE == 4) return r * TW + c;
   ok = (((r + kh) | (c + kw)) & 1) == 0;
-  return ((r + kh) >> 1) * HaloB<3>::W + ((c + kw) >> 1);
+  return ((r + kh) >> 1) * HaloB<3, TH>::W + ((c + kw) >> 1);
 }
 template <int MODE>
 __device__ __forceinline__ void halo_origin_b(int oy0, int ox0, int& iy0, int& ix0) {
@@ -56,20 +57,22 @@ __device__ __forceinline__ void halo_origin_b(int oy0, int ox0, int& iy0, int& i
   else { iy0 = oy0 / 2 - 1; ix0 = ox0 / 2 - 1; }
 }
 
-// WCT x WPT MFMA tiles per wave (channel tiles x pixel tiles), WAVES_CO x WAVES_PX waves; WAVES_PX * WPT = 4 pixel tiles
-template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX>
+// WCT x WPT MFMA tiles per wave (channel tiles x pixel tiles), WAVES_CO x WAVES_PX waves; WAVES_PX * WPT pixel tiles of 32 = the
+// TH x 16 block tile.  The wide form (TH = 16: 64 co x 128 px per wave) halves the weight-fragment traffic per MFMA: with 2 x 2
+// tiles every MFMA needs 512 B of weights through the vector L1 (64 B/clk per CU) -- as many cycles as the MFMAs themselves.
+template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX, int TH>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
-  static_assert(WAVES_CO * WAVES_PX == 4 && WAVES_PX * WPT == 4, "tile layout");
+  static_assert(WAVES_CO * WAVES_PX == 4 && WAVES_PX * WPT * 32 == TH * TW, "tile layout");
   constexpr int BCO = WAVES_CO * WCT * 32;
   constexpr int HS = KC + 8;                           // halo row stride in bf16 (16 bytes of padding: conflict-free b128 reads)
-  constexpr int HPIX = HaloB<MODE>::H * HaloB<MODE>::W;
+  constexpr int HPIX = HaloB<MODE, TH>::H * HaloB<MODE, TH>::W;
   constexpr int VC = KC / 8;                           // 16-byte vectors per halo pixel
   constexpr int HALO_V = HPIX * VC;
   constexpr int HALO_IT = (HALO_V + 255) / 256;
-  constexpr int TAPS = HaloB<MODE>::TAPS;
+  constexpr int TAPS = HaloB<MODE, TH>::TAPS;
   constexpr int KS = KC / 16;                          // MFMA k-steps per tap and chunk
   constexpr int NIT = TAPS * KS;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * HPIX * HS];
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];   // 2 * HPIX * HS bf16 (two halo stages; 93 KB in the wide form)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave / WAVES_PX, wpx = wave % WAVES_PX;
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
   const int co0 = blockIdx.y * BCO;
   int iy0, ix0;
   halo_origin_b<MODE>(oy0, ox0, iy0, ix0);
+  static_assert(MODE == 0 || MODE == 4 || TH == 8, "the wide tile is only built for modes 0 and 4");
 
   const int esz = p.out_f32 ? 4 : 2;
   const unsigned OOB = 0x7FFFFFF0u;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
     for (int i = 0; i < HALO_IT; ++i) {
       const int f = tid + 256 * i;
       const int hp = f / VC, q = f % VC;
-      const int iy = iy0 + hp / HaloB<MODE>::W, ix = ix0 + hp % HaloB<MODE>::W;
+      const int iy = iy0 + hp / HaloB<MODE, TH>::W, ix = ix0 + hp % HaloB<MODE, TH>::W;
       const int c = c0 + 8 * q;
       const bool ok = f < HALO_V && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin;
       const unsigned voff = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + c) * 2) : OOB;
@@ -149,14 +153,20 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
   };
 
   // ---- operand fetch ------------------------------------------------------------------------------------------------------
-  const u32x4* wq = reinterpret_cast<const u32x4*>(p.wpk);
+  // Weight fragments: fragment index ((tap * KT + kt) * CT + ct), 1 KiB each, lane-linear.  Branch-free buffer loads: a step past
+  // the last chunk reads another tap's (unused) fragment or, past the pack, zeros -- never a guarded load (hipcc branches around
+  // those and waits vmcnt(0) at every join).
   const int KT = p.CinP / 16, CT = p.CoutP / 32;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.wpk), 0, TAPS * KT * CT * 1024, 0x00020000);
   const int ct0 = co0 / 32 + wco * WCT;
-  auto load_a = [&](int ch, int it, bf16x8 (&a)[WCT]) {   // weight fragments of step `it` of chunk `ch`
-    const int tap = it / KS, ks = it % KS;
-    const int64_t base = ((int64_t)(tap * KT + ch * KS + ks) * CT + ct0) * 64 + lane;
+  const unsigned lane16 = lane * 16;
+  auto load_a = [&](int ch, int it, bf16x8 (&a)[WCT]) {   // step `it` of chunk `ch`; it >= NIT runs into chunk ch + 1
+    const int c2 = ch + it / NIT, i2 = it % NIT;
+    const int tap = i2 / KS, ks = i2 % KS;
+    const unsigned base = (unsigned)(((tap * KT + c2 * KS + ks) * CT + ct0) * 1024) + lane16;
 #pragma unroll
-    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(wq[base + ct * 64]);
+    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, base + ct * 1024, 0, 0));
   };
   auto load_b = [&](const bf16_t* Hs, int it, bf16x8 (&b)[WPT]) {
     const int tap = it / KS, ks = it % KS;
@@ -164,22 +174,22 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
 #pragma unroll
     for (int pt = 0; pt < WPT; ++pt) {
       bool ok;
-      const int hp = halo_index_b<MODE>(prr[pt], pcc[pt], kh, kw, ok);
+      const int hp = halo_index_b<MODE, TH>(prr[pt], pcc[pt], kh, kw, ok);
       u32x4 v = *reinterpret_cast<const u32x4*>(Hs + hp * HS + 16 * ks + 8 * h);
       if (MODE == 3 && !ok) v = u32x4{0u, 0u, 0u, 0u};
       b[pt] = frag_from_u32x4(v);
     }
   };
 
+  // Register rings with compile-time slots (the step loop is fully unrolled): weights RA - 1 steps ahead (L2 latency), pixels one
+  // step ahead (LDS); no rotation copies.  NIT % RA == 0 keeps the weight slots the same in every chunk.
+  constexpr int RA = (NIT % 3 == 0) ? 3 : 2, PA = RA - 1;
+  static_assert(NIT % RA == 0, "weight ring");
   const int nchunks = p.CinP / KC;
-  bf16x8 ac[WCT], an[WCT], an2[WCT], bc[WPT], bn[WPT];
-  auto load_a_step = [&](int ch, int it, bool more, bf16x8 (&a)[WCT]) {   // step `it` may run into chunk ch + 1
-    if (it < NIT) load_a(ch, it, a);
-    else if (more) load_a(ch + 1, it - NIT, a);
-  };
+  bf16x8 abuf[RA][WCT], bbuf[2][WPT];
   load_halo(0);
-  load_a(0, 0, ac);
-  load_a_step(0, 1, nchunks > 1, an);
+#pragma unroll
+  for (int j = 0; j < PA; ++j) load_a(0, j, abuf[j]);
   store_halo(smem);
   __syncthreads();
 
@@ -187,19 +197,19 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
     const bf16_t* Hs = smem + (ch & 1) * HPIX * HS;
     const bool more = ch + 1 < nchunks;
     if (more) load_halo((ch + 1) * KC);
-    load_b(Hs, 0, bc);
+    load_b(Hs, 0, bbuf[0]);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      load_a_step(ch, it + 2, more, an2);       // weights two steps ahead (L2 latency), pixels one step ahead (LDS)
-      if (it + 1 < NIT) load_b(Hs, it + 1, bn);
+      // pinned: hipcc otherwise sinks the prefetches down to their first use (a weight load followed a few instructions later by
+      // the vmcnt(0) that waits for it: one L2 round trip per step)
+      load_a(ch, it + PA, abuf[(it + PA) % RA]);
+      if (it + 1 < NIT) load_b(Hs, it + 1, bbuf[(it + 1) % 2]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < WCT; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(ac[ct], bc[pt], acc[ct][pt]);
-#pragma unroll
-      for (int ct = 0; ct < WCT; ++ct) { ac[ct] = an[ct]; an[ct] = an2[ct]; }
-#pragma unroll
-      for (int pt = 0; pt < WPT; ++pt) bc[pt] = bn[pt];
+        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(abuf[it % RA][ct], bbuf[it % 2][pt], acc[ct][pt]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_halo(smem + ((ch + 1) & 1) * HPIX * HS);
     __syncthreads();
@@ -259,17 +269,35 @@ __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int
 
 int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX>
+template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX, int TH>
 void launch_cfg(const ConvB& p, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX>), grid, dim3(256), 0, st, p);
+  constexpr int bytes = 2 * HaloB<MODE, TH>::H * HaloB<MODE, TH>::W * (KC + 8) * 2;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX, TH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    once = true;
+  }
+  hipLaunchKernelGGL((conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX, TH>), grid, dim3(256), bytes, st, p);
 }
 
 template <int MODE, int KC>
-void launch_by_cout(const ConvB& p, hipStream_t st) {
+void launch_by_cout(ConvB& p, hipStream_t st) {
+  // A/B switch.  Measured (bench.py --bf16, B=32, 256x256): the wide tile runs the family at 365 TFLOP/s against 646 for the
+  // 128-pixel tile -- one 4-wave block per CU (424 registers, 93 KB of LDS) has nothing to overlap its prologue, barriers and
+  // epilogue with, which costs more than the halved weight traffic saves.  Off by default.
+  static const bool wide = getenv("ODVAE_CONV_BF16_WIDE") != nullptr;
+  if constexpr (MODE == 0 || MODE == 4) {
+    if (p.Cout > 64 && p.Ho >= 16 && wide) {     // wide tile: 16 x 16 pixels x 128 channels, 64 co x 128 px per wave
+      p.tiles_y = ceil_div(p.Ho, 16);
+      launch_cfg<MODE, KC, 2, 4, 2, 2, 16>(p, dim3(p.N * p.tiles_x * p.tiles_y, ceil_div(p.Cout, 128)), st);
+      return;
+    }
+  }
   const int tiles = p.N * p.tiles_x * p.tiles_y;
-  if (p.Cout > 64)      launch_cfg<MODE, KC, 2, 2, 2, 2>(p, dim3(tiles, ceil_div(p.Cout, 128)), st);
-  else if (p.Cout > 32) launch_cfg<MODE, KC, 2, 1, 1, 4>(p, dim3(tiles, 1), st);
-  else                  launch_cfg<MODE, KC, 1, 1, 1, 4>(p, dim3(tiles, 1), st);
+  if (p.Cout > 64)      launch_cfg<MODE, KC, 2, 2, 2, 2, 8>(p, dim3(tiles, ceil_div(p.Cout, 128)), st);
+  else if (p.Cout > 32) launch_cfg<MODE, KC, 2, 1, 1, 4, 8>(p, dim3(tiles, 1), st);
+  else                  launch_cfg<MODE, KC, 1, 1, 1, 4, 8>(p, dim3(tiles, 1), st);
 }
 
 }  // namespace
@@ -315,14 +343,14 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   else if (mode == 1) { eh = (Hi - 2) / 2 + 1; ew = (Wi - 2) / 2 + 1; }   // (H + 1 - 3)/2 + 1 with the (0,1,0,1) pad
   else { eh = 2 * Hi; ew = 2 * Wi; }
   ODVAE_CHECK_ARG(Ho == eh && Wo == ew, "conv_bf16(mode %d): output %dx%d does not match input %dx%d (expected %dx%d)", mode, Ho, Wo, Hi, Wi, eh, ew);
-  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 2 < 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * 4 < 0x7FFFFFF0ll,
+  ODVAE_CHECK_ARG((int64_t)Hi * Wi * Cin * 2 <= 0x7FFFFFF0ll && (int64_t)Ho * Wo * Cout * (out_f32 ? 4 : 2) <= 0x7FFFFFF0ll,
                   "conv_bf16: one image exceeds the 2 GiB buffer-descriptor range");
   ConvB p;
   p.x = static_cast<const bf16_t*>(x); p.wpk = static_cast<const bf16_t*>(pack); p.bias = bias;
   p.residual = static_cast<const bf16_t*>(residual); p.y = y;
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.CinP = odvae_conv_bf16_reduce_pad(Cin); p.CoutP = odvae_conv_bf16_out_pad(Cout);
-  p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, TH); p.out_f32 = out_f32;
+  p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, 8); p.out_f32 = out_f32;
   ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool k64 = p.CinP % 64 == 0;

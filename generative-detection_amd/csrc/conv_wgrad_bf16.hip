@@ -21,6 +21,7 @@ struct WgradB {
   const bf16_t* x;    // [N][Hi][Wi][Cin]
   const bf16_t* dy;   // [N][Ho][Wo][Cout]
   float* slab;        // [splits][taps][CoutP][CinP]
+  float* bslab;       // [splits][CoutP] per-split column sums of dy (bias gradient), or null
   int N, Hi, Wi, Cin, Ho, Wo, Cout, CinP, CoutP;
   int tiles_x, tiles_y, ntiles, splits;
 };
@@ -64,6 +65,30 @@ __global__ __launch_bounds__(COT * CIT * 64) void conv_wgrad_bf16_kernel(WgradB 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+  // bias gradient rides along: the waves of the first ci tile already hold dy^T fragments; one more MFMA against a tile of ones
+  // sums them over the pixels (a VALU sum of the fragment cost 16 instructions per k-step and 20 % of the kernel)
+  const bool do_bias = p.bslab != nullptr && cit == 0 && blockIdx.z == 0;
+  f32x16 bacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bacc[i] = 0.f;
+  const bf16x8 ones = frag_from_u32x4(u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});   // eight bf16 1.0
+
+  // Per-thread constants of the staging loads (which tile pixel / halo pixel and channel octet each of its vectors is): the
+  // per-tile work is then a few compares and one add per 16-byte load instead of 64-bit index arithmetic (the first version
+  // spent ~30 VALU instructions per load, 210 per tile against 72 MFMAs).
+  int d_r[D_IT], d_c[D_IT], d_rel[D_IT], x_r[X_IT], x_c[X_IT], x_rel[X_IT];
+#pragma unroll
+  for (int i = 0; i < D_IT; ++i) {
+    const int f = tid + NT * i, px = f / (BCO / 8), c = co0 + 8 * (f % (BCO / 8));
+    d_r[i] = px / TW; d_c[i] = px % TW;
+    d_rel[i] = (f < DV && c < p.Cout) ? ((d_r[i] * p.Wo + d_c[i]) * p.Cout + c) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int f = tid + NT * i, hp = f / (BCI / 8), c = ci0 + 8 * (f % (BCI / 8));
+    x_r[i] = hp / HaloW<MODE, TH>::W; x_c[i] = hp % HaloW<MODE, TH>::W;
+    x_rel[i] = (f < XV && c < p.Cin) ? ((x_r[i] * p.Wi + x_c[i]) * p.Cin + c) : -1;
+  }
   u32x4 dreg[D_IT], xreg[X_IT];
   auto fetch = [&](int tile) {
     int t = tile;
@@ -79,21 +104,17 @@ __global__ __launch_bounds__(COT * CIT * 64) void conv_wgrad_bf16_kernel(WgradB 
         const_cast<bf16_t*>(p.dy + (int64_t)n * p.Ho * p.Wo * p.Cout), 0, p.Ho * p.Wo * p.Cout * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin), 0, p.Hi * p.Wi * p.Cin * 2, 0x00020000);
+    const int dbase = (oy0 * p.Wo + ox0) * p.Cout, xbase = (iy0 * p.Wi + ix0) * p.Cin;
+    const int rows_left = p.Ho - oy0, cols_left = p.Wo - ox0;
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
-      const int f = tid + NT * i;
-      const int px = f / (BCO / 8), q = f % (BCO / 8);
-      const int oy = oy0 + px / TW, ox = ox0 + px % TW, c = co0 + 8 * q;
-      const bool ok = f < DV && oy < p.Ho && ox < p.Wo && c < p.Cout;
-      dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(drsrc, ok ? (unsigned)(((oy * p.Wo + ox) * p.Cout + c) * 2) : OOB, 0, 0);
+      const bool ok = d_rel[i] >= 0 && d_r[i] < rows_left && d_c[i] < cols_left;
+      dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(drsrc, ok ? (unsigned)((dbase + d_rel[i]) * 2) : OOB, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
-      const int f = tid + NT * i;
-      const int hp = f / (BCI / 8), q = f % (BCI / 8);
-      const int iy = iy0 + hp / HaloW<MODE, TH>::W, ix = ix0 + hp % HaloW<MODE, TH>::W, c = ci0 + 8 * q;
-      const bool ok = f < XV && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi && c < p.Cin;
-      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + c) * 2) : OOB, 0, 0);
+      const bool ok = x_rel[i] >= 0 && (unsigned)(iy0 + x_r[i]) < (unsigned)p.Hi && (unsigned)(ix0 + x_c[i]) < (unsigned)p.Wi;
+      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)((xbase + x_rel[i]) * 2) : OOB, 0, 0);
     }
   };
   auto stage = [&]() {
@@ -126,6 +147,7 @@ __global__ __launch_bounds__(COT * CIT * 64) void conv_wgrad_bf16_kernel(WgradB 
     for (int r = 0; r < TH; ++r) {
       const int c_lo = 8 * hk + q, c_hi = c_lo + 4;     // tile column (= pixel within the 16-pixel k-step) of the two reads
       const bf16x8 a = frag_from_tr(lds_read_tr16(Ds + (r * TW + c_lo) * DS + dcol), lds_read_tr16(Ds + (r * TW + c_hi) * DS + dcol));
+      if (do_bias) bacc = mfma_bf16(a, ones, bacc);   // wave-uniform; every column of bacc = sum over the 16 pixels of dy^T rows
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int kh = TAPS == 1 ? 0 : t / 3, kw = TAPS == 1 ? 0 : t % 3;
@@ -140,6 +162,10 @@ __global__ __launch_bounds__(COT * CIT * 64) void conv_wgrad_bf16_kernel(WgradB 
   // slab [split][tap][CoutP][CinP]: register i of lane (r, h) is dW[co = 32 cot + (i&3) + 8(i>>2) + 4h][ci = 32 cit + r]
   float* slab = p.slab + (int64_t)blockIdx.x * TAPS * p.CoutP * p.CinP;
   const int li = lane & 31, h = lane >> 5;
+  if (do_bias && li == 0) {   // column 0 of the (all columns equal) sum tile: rows = channels
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p.bslab[(int64_t)blockIdx.x * p.CoutP + co0 + cot * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = bacc[i];
+  }
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -151,8 +177,14 @@ __global__ __launch_bounds__(COT * CIT * 64) void conv_wgrad_bf16_kernel(WgradB 
 
 // dw[co][ci][tap] (OIHW) = sum over splits of slab[s][tap][co][ci]
 __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ slab, int splits, int taps, int Cout, int Cin, int CoutP, int CinP,
-                                         float* __restrict__ dw) {
+                                         float* __restrict__ dw, const float* __restrict__ bslab, float* __restrict__ db) {
   const int64_t per = (int64_t)taps * CoutP * CinP;
+  if (db && blockIdx.x == 0)
+    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += bslab[(int64_t)k * CoutP + co];
+      db[co] = s;
+    }
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (int64_t)gridDim.x * blockDim.x) {
     const int ci = (int)(idx % CinP);
     const int co = (int)((idx / CinP) % CoutP);
@@ -204,13 +236,14 @@ extern "C" {
 size_t odvae_conv_wgrad_bf16_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout) {
   Plan pl;
   if (!make_plan(mode, N, Ho, Wo, Cin, Cout, pl)) return 0;
-  return (size_t)pl.splits * (mode == 4 ? 1 : 9) * pl.CoutP * pl.CinP * sizeof(float);
+  return ((size_t)pl.splits * (mode == 4 ? 1 : 9) * pl.CoutP * pl.CinP + (size_t)pl.splits * pl.CoutP) * sizeof(float);
 }
 
 // dw f32 OIHW [Cout][Cin][k][k] (k*k = 9, or 1 for mode 4) from x bf16 [N][Hi][Wi][Cin] and dy bf16 [N][Ho][Wo][Cout];
-// Cin % 8 == 0 and Cout % 8 == 0 (16-byte channel vectors).  Deterministic (fixed slab order).
+// Cin % 8 == 0 and Cout % 8 == 0 (16-byte channel vectors).  db f32 [Cout] = per-channel sum of dy (bias gradient) or NULL: it rides
+// along in the same pass over dy.  Deterministic (fixed slab order).
 int odvae_conv_wgrad_bf16(int mode, const void* x, const void* dy, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout,
-                          float* dw, void* workspace, size_t workspace_bytes, void* stream) {
+                          float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
   Plan pl;
   ODVAE_CHECK_ARG(x && dy && dw && N > 0 && Cin > 0 && Cout > 0, "conv_wgrad_bf16: null or empty operand");
   ODVAE_CHECK_ARG(make_plan(mode, N, Ho, Wo, Cin, Cout, pl), "conv_wgrad_bf16: unsupported mode %d / shape", mode);
@@ -230,6 +263,7 @@ int odvae_conv_wgrad_bf16(int mode, const void* x, const void* dy, int N, int Hi
   }
   WgradB p;
   p.x = static_cast<const bf16_t*>(x); p.dy = static_cast<const bf16_t*>(dy); p.slab = static_cast<float*>(workspace);
+  p.bslab = db ? p.slab + (size_t)pl.splits * (mode == 4 ? 1 : 9) * pl.CoutP * pl.CinP : nullptr;
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.CinP = pl.CinP; p.CoutP = pl.CoutP;
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.splits = pl.splits;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -248,7 +282,7 @@ int odvae_conv_wgrad_bf16(int mode, const void* x, const void* dy, int N, int Hi
   const int taps = mode == 4 ? 1 : 9;
   const int64_t per = (int64_t)taps * pl.CoutP * pl.CinP;
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(per, 256), 2048)), dim3(256), 0, st,
-                     p.slab, pl.splits, taps, Cout, Cin, pl.CoutP, pl.CinP, dw);
+                     p.slab, pl.splits, taps, Cout, Cin, pl.CoutP, pl.CinP, dw, p.bslab, db);
   ODVAE_LAUNCH_CHECK("conv_wgrad_bf16 reduce");
   return ODVAE_OK;
 }

@@ -78,7 +78,7 @@ PROTOTYPES = {
     "odvae_conv_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "odvae_conv_bf16": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv_wgrad_bf16_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "odvae_conv_wgrad_bf16": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
+    "odvae_conv_wgrad_bf16": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "odvae_flash_attn_supported": (_I, [_I, _I, _I]),
     "odvae_flash_attn_fwd_bf16": (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     "odvae_flash_attn_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),

@@ -56,6 +56,7 @@ class _KernelEvents:
         self.extra = False    # also bracket the secondary kernel families (bench.py: one extra step after the timed region)
         self.rec = {}
         self.issued = 0.0
+        self.sample, self._n = 1, 0
 
     def enable(self):
         self.on, self.rec, self.issued = True, {}, 0.0
@@ -72,6 +73,10 @@ class _KernelEvents:
     def begin(self, secondary=False):
         if not self.on or (secondary and not self.extra):
             return None
+        if not secondary and self.sample > 1:   # bracket one launch in `sample` of the dominant family (see bench.py)
+            self._n += 1
+            if self._n % self.sample:
+                return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
@@ -1044,9 +1049,12 @@ class _ConvB(Function):
                 du = _conv_b_raw(0, dyb, ctx.dpack, cin, None, None, False)
                 dx = _new_cl(n, cin, hi, wi, x, dtype=BF16)
                 _lib.check(L.odvae_upsample2x_bwd_bf16(du.data_ptr(), dx.data_ptr(), n, hi, wi, cin, _lib.stream_ptr()), "upsample2x_bwd_bf16")
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        fold_db = want_db and dy.dtype == BF16 and ctx.needs_input_grad[1]   # bias gradient rides in the weight-gradient pass over dy
         if ctx.needs_input_grad[1]:
             taps = ctx.wshape[2] * ctx.wshape[3]
             dwf = torch.empty((cp, cx) + tuple(ctx.wshape[2:]), dtype=torch.float32, device=x.device)
+            dbf = torch.empty(cp, dtype=torch.float32, device=x.device) if fold_db else None
             if mode == 4:
                 per = hi * wi
                 grp = max(1, min(n, _I31 // (per * max(cx, cp) * 2)))
@@ -1060,12 +1068,14 @@ class _ConvB(Function):
             need = L.odvae_conv_wgrad_bf16_workspace_bytes(mode, geo[0], geo[4], geo[5], cx, cp)
             wp, wn = _ws(need, x)
             tag = KERNEL_EVENTS.begin(secondary=True)
-            _lib.check(L.odvae_conv_wgrad_bf16(mode, x.data_ptr(), dyb.data_ptr(), *geo, dwf.data_ptr(), wp, wn, _lib.stream_ptr()),
-                       "conv_wgrad_bf16(mode=%d)" % mode)
+            _lib.check(L.odvae_conv_wgrad_bf16(mode, x.data_ptr(), dyb.data_ptr(), *geo, dwf.data_ptr(), _lib.ptr(dbf), wp, wn,
+                                               _lib.stream_ptr()), "conv_wgrad_bf16(mode=%d)" % mode)
             KERNEL_EVENTS.end("conv_wgrad_bf16", 2.0 * taps * cx * cp * n * ho * wo, tag, 2.0 * n * (hi * wi * cx + ho * wo * cp))
             dw = dwf if (cp == cout and cx == cin) else dwf[:cout, :cin].contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            if dy.dtype != BF16:
+            if fold_db:
+                db = dbf if cp == cout else dbf[:cout].contiguous()
+        if want_db and not fold_db:
+            if dy.dtype != BF16:   # f32 upstream gradient (reconstruction / moments): sum the f32 values themselves
                 db = _colsum(_cl(dy), n * ho * wo, cout)
             else:
                 db = torch.empty(cout, dtype=torch.float32, device=x.device)

@@ -217,8 +217,9 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
                     const void* residual, void* y, int Ho, int Wo, int out_f32, void* stream);
 /* ---- conv_wgrad_bf16.hip: weight gradient, dw f32 OIHW, modes 0 / 1 / 2 / 4 as above; deterministic ---------------------------- */
 size_t odvae_conv_wgrad_bf16_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout);
+/* db f32 [Cout] (bias gradient = per-channel sum of dy) or NULL, produced in the same pass */
 int odvae_conv_wgrad_bf16(int mode, const void* x, const void* dy, int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout,
-                          float* dw, void* workspace, size_t workspace_bytes, void* stream);
+                          float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 /* ---- flash_attn_bf16.hip: fused single-head attention ([UPSTREAM] AttnBlock.forward), scores never in HBM --------------------- */
 int odvae_flash_attn_supported(int N, int T, int C);
 /* qkv [N][T][3C] (q | k | v) -> o [N][T][C], lse2 f32 [N][T] = log2 sum_j exp(score_ij * scale) */

@@ -171,6 +171,12 @@ def test_flash_attention_bf16(hip_lib, n, c, h, w):
     assert o.dtype == BF
     close(o, o_ref, BF_TOL, "attention o")
     o.backward(cl_bf16(do))
+    # the kernels are deterministic (no atomics; dQ has its own kernel): a second run is bit-identical -- also a race screen for
+    # the double-buffered LDS pipeline
+    q2 = cl_bf16(qkv.detach()).requires_grad_(True)
+    o2 = ops.attention_qkv(q2)
+    o2.backward(cl_bf16(do))
+    assert torch.equal(o2, o) and torch.equal(q2.grad, qd.grad), "attention is not bit-reproducible"
     dref = qkv.grad
     # dq / dk / dv have very different magnitudes: compare each against its own scale
     for name, sl in (("dq", slice(0, c)), ("dk", slice(c, 2 * c)), ("dv", slice(2 * c, 3 * c))):

@@ -24,7 +24,7 @@ def main(path):
         k = k.split("(")[0] if not k.startswith("at::") else k[:70]
         by[k] += (b - a) / 1e6
         cnt[k] += 1
-    print("# rocprofv3 --kernel-trace, last training step of `bench.py` (B=32, 256x256, fp32, rec+KL only)\n")
+    print("# rocprofv3 --kernel-trace, last training step of `bench.py` (%s)\n" % (sys.argv[2] if len(sys.argv) > 2 else "B=32, 256x256, fp32, rec+KL only"))
     print("step wall %.1f ms | kernel busy %.1f ms | idle %.1f ms | %d launches\n" % (wall, busy, wall - busy, len(seg)))
     print("| kernel | launches | total ms | avg us | % of busy |\n|---|---:|---:|---:|---:|")
     for k, v in by.most_common(40):
