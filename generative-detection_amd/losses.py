@@ -136,6 +136,9 @@ class PoseLoss(LPIPSWithDiscriminator):
         if self.train_on_yaw:
             self.rot_loss_fn = nn.SmoothL1Loss(reduction="none")
         self.class_loss_fn = SigmoidFocalLoss()
+        # True: every pose-head term from one HIP kernel (ops.pose_losses); False keeps the per-term torch-op methods below (same
+        # values; tests compare the two)
+        self.fused_pose_terms = True
         self.bbox_loss_fn = nn.MSELoss(reduction="none")
         self.fill_factor_loss_fn = nn.MSELoss(reduction="none")
         # `dataset_stats` (a dict) is an extension for runs without the pickle, which the reference does not ship
@@ -210,6 +213,21 @@ class PoseLoss(LPIPSWithDiscriminator):
             self._prior_cache = cache
         return cache
 
+    def _fused_pose_terms(self, dec_pose, pose_gt, bbox_gt, fill_factor_gt, class_gt, class_gt_label, bbox_posterior):
+        """out[9] of ops.pose_losses: the translation / yaw / class / box-size / fill-factor terms and the box-posterior KL of
+        compute_pose_loss, compute_class_loss, compute_bbox_loss, compute_fill_factor_loss and compute_pose_kl_loss in one launch."""
+        dev = dec_pose.device
+        cache = getattr(self, "_prior_pack", None)
+        if cache is None or cache[1].device != dev:
+            rows, p_mean, p_var, p_logvar = self._prior_table(dev)
+            cache = (rows, torch.stack([p_mean, p_var, p_logvar], dim=1).contiguous())     # [L, 3, 8]
+            self._prior_pack = cache
+        rows, prior = cache
+        idx = _lib.upload(torch.tensor([rows[l] if l != "background" else -1 for l in class_gt_label], dtype=torch.int32), dev)
+        return ops.pose_losses(dec_pose, bbox_posterior.parameters, pose_gt, bbox_gt, fill_factor_gt.reshape(-1), class_gt, prior, idx,
+                               bg_idx=BACKGROUND_CLASS_IDX, l2=not isinstance(self.pose_loss, nn.L1Loss), yaw=self.train_on_yaw,
+                               gamma=self.class_loss_fn.gamma, alpha=self.class_loss_fn.alpha)
+
     def compute_pose_kl_loss(self, bbox_posterior, mask_bg, class_gt):
         """The reference loops over the batch on the host (:196-203), calling kl(other) on [8,1] moments against
         [1,8] prior moments.  QUIRK kept: that broadcast makes entry i of a sample's row the sum over ALL prior
@@ -272,18 +290,28 @@ class PoseLoss(LPIPSWithDiscriminator):
         lhw_rec = dec_pose[:, POSE_6D_DIM:POSE_6D_DIM + LHW_DIM]
         fill_factor_rec = dec_pose[:, POSE_6D_DIM + LHW_DIM:BBOX_DIM]
         class_probs = dec_pose[:, BBOX_DIM:]
-        class_loss, weighted_class_loss = self.compute_class_loss(class_gt, class_probs)
-        bbox_loss, weighted_bbox_loss = self.compute_bbox_loss(bbox_gt, lhw_rec, mask_bg)
-        # QUIRK (:269): (gt, pred) are passed into the (pred, gt) slots; symmetric for l1/l2
-        pose_loss, weighted_pose_loss, t1_loss, t2_loss, t3_loss, v3_loss = self.compute_pose_loss(pose_gt, pose_rec, mask_bg)
+        fused = self.fused_pose_terms and dec_pose.is_cuda and dec_pose.dim() == 2 and bbox_posterior.parameters.shape == (dec_pose.shape[0], 2 * BBOX_DIM)
+        if fused:
+            # all pose-head terms (and their gradients) from one kernel: pose_f32.hip
+            terms = self._fused_pose_terms(dec_pose, pose_gt, bbox_gt, fill_factor_gt, class_gt, class_gt_label, bbox_posterior)
+            pose_loss, class_loss, bbox_loss, fill_factor_loss, kl_loss_obj_bbox = terms[0], terms[1], terms[2], terms[3], terms[4]
+            t1_loss, t2_loss, t3_loss, v3_loss = terms[5], terms[6], terms[7], terms[8]
+            weighted_pose_loss, weighted_class_loss = self.pose_weight * pose_loss, self.class_weight * class_loss
+            weighted_bbox_loss, weighted_fill_factor_loss = self.bbox_weight * bbox_loss, self.fill_factor_weight * fill_factor_loss
+        else:
+            class_loss, weighted_class_loss = self.compute_class_loss(class_gt, class_probs)
+            bbox_loss, weighted_bbox_loss = self.compute_bbox_loss(bbox_gt, lhw_rec, mask_bg)
+            # QUIRK (:269): (gt, pred) are passed into the (pred, gt) slots; symmetric for l1/l2
+            pose_loss, weighted_pose_loss, t1_loss, t2_loss, t3_loss, v3_loss = self.compute_pose_loss(pose_gt, pose_rec, mask_bg)
+            fill_factor_loss, weighted_fill_factor_loss = self.compute_fill_factor_loss(fill_factor_gt, fill_factor_rec.squeeze(), mask_bg)
         mask_loss, weighted_mask_loss = self.get_mask_loss(None, None, mask_bg)
-        fill_factor_loss, weighted_fill_factor_loss = self.compute_fill_factor_loss(fill_factor_gt, fill_factor_rec.squeeze(), mask_bg)
 
         rec_sums, chw = self._rec_sums(rgb_gt, recon_rgb, mask_2d_bbox, use_pixel_loss)
         nll_loss, weighted_nll_loss = self._get_nll_loss(rec_sums, chw, mask_bg, weights)
         rec_mean = rec_sums.detach().sum() / (rec_sums.numel() * chw)
         kl_loss_obj = self._get_kl_loss(posterior_obj, mask_bg)
-        kl_loss_obj_bbox = self.compute_pose_kl_loss(bbox_posterior, mask_bg, class_gt_label)
+        if not fused:
+            kl_loss_obj_bbox = self.compute_pose_kl_loss(bbox_posterior, mask_bg, class_gt_label)
         bg4 = mask_bg.reshape(-1, 1, 1, 1)
 
         if optimizer_idx == 0:

@@ -1207,3 +1207,50 @@ class _FlashAttention(Function):
         # algorithmic: the five products of the backward (S, dP, dV, dK, dQ); issued: seven (S and dP are formed in both kernels)
         KERNEL_EVENTS.end("flash_attn", 10.0 * t * t * c * n, tag, 2.0 * n * t * 8 * c, issued=14.0 * t * t * c * n)
         return dqkv
+
+
+# ------------------------------------------------------------------------------------------------------
+# pose head: every loss term in one launch (pose_f32.hip)
+# ------------------------------------------------------------------------------------------------------
+class _PoseLosses(Function):
+    """out[9] = pose, class, bbox, fill, kl_bbox losses + the logged per-component means (t1, t2, t3, v3) of
+    src/modules/losses/contperceptual.py:111-132,176-212.  Differentiable w.r.t. dec_pose and the box-posterior moments."""
+
+    @staticmethod
+    def forward(ctx, dec_pose, moments, pose_gt, bbox_gt, fill_gt, class_gt, prior, prior_idx, bg_idx, l2, yaw, gamma, alpha):
+        L = _L()
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        dec_pose, moments, pose_gt, bbox_gt, fill_gt, prior = (f32(t) for t in (dec_pose, moments, pose_gt, bbox_gt, fill_gt, prior))
+        _lib.require_device(dec_pose, moments, pose_gt, bbox_gt, fill_gt, prior)
+        class_gt = class_gt.detach().to(torch.int64).contiguous()
+        prior_idx = prior_idx.detach().to(torch.int32).contiguous()
+        b, w = dec_pose.shape
+        nc = w - 8
+        if moments.shape != (b, 16) or pose_gt.shape != (b, 4) or bbox_gt.shape != (b, 3) or fill_gt.numel() != b or prior.shape[1:] != (3, 8):
+            raise ValueError("pose_losses: unexpected shapes %s %s %s %s %s %s" % tuple(tuple(t.shape) for t in (dec_pose, moments, pose_gt, bbox_gt, fill_gt, prior)))
+        out = torch.empty(9, dtype=torch.float32, device=dec_pose.device)
+        jac_pose = torch.empty(4, b, w, dtype=torch.float32, device=dec_pose.device)
+        jac_mom = torch.empty(b, 16, dtype=torch.float32, device=dec_pose.device)
+        _lib.check(L.odvae_pose_losses_f32(dec_pose.data_ptr(), pose_gt.data_ptr(), bbox_gt.data_ptr(), fill_gt.data_ptr(), class_gt.data_ptr(),
+                                           moments.data_ptr(), prior.data_ptr(), prior_idx.data_ptr(), b, nc, prior.shape[0], int(bg_idx), int(l2),
+                                           int(yaw), float(gamma), float(alpha), out.data_ptr(), jac_pose.data_ptr(), jac_mom.data_ptr(),
+                                           _lib.stream_ptr()), "pose_losses")
+        ctx.save_for_backward(jac_pose, jac_mom)
+        ctx.dims = (b, nc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _L()
+        jac_pose, jac_mom = ctx.saved_tensors
+        b, nc = ctx.dims
+        g = g.contiguous()
+        d_pose = torch.empty(b, 8 + nc, dtype=torch.float32, device=g.device)
+        d_mom = torch.empty(b, 16, dtype=torch.float32, device=g.device)
+        _lib.check(L.odvae_pose_losses_bwd_f32(g.data_ptr(), jac_pose.data_ptr(), jac_mom.data_ptr(), b, nc, d_pose.data_ptr(), d_mom.data_ptr(),
+                                               _lib.stream_ptr()), "pose_losses_bwd")
+        return (d_pose, d_mom) + (None,) * 11
+
+
+def pose_losses(dec_pose, moments, pose_gt, bbox_gt, fill_gt, class_gt, prior, prior_idx, bg_idx=1, l2=False, yaw=True, gamma=2.0, alpha=0.25):
+    return _PoseLosses.apply(dec_pose, moments, pose_gt, bbox_gt, fill_gt, class_gt, prior, prior_idx, bg_idx, l2, yaw, gamma, alpha)

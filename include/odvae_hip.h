@@ -199,6 +199,17 @@ int odvae_patch_table_ints(int S);
 int odvae_patch_crop_resize_u8(const void* d_images, const void* d_geom, const void* d_mask_rect, const void* d_tables,
                                int n_slots, int B, int S, void* patch, void* mask, void* stream);
 
+/* ---- pose_f32.hip: every pose-head loss term in one launch (src/modules/losses/contperceptual.py:111-132,176-212) ------------- */
+/* dec_pose [B][8+NC] (pose 4 | lhw 3 | fill 1 | class logits), moments [B][16] (box posterior mean | raw logvar), prior [L][3][8]
+   (mean | var | logvar per label), prior_idx [B] (< 0 = label "background").  out [9] = pose, class, bbox, fill, kl_bbox, mean t1, t2,
+   t3, v3; jac_pose [4][B][8+NC] and jac_mom [B][16] = Jacobians of out[0..3] / out[4] for odvae_pose_losses_bwd_f32 */
+int odvae_pose_losses_f32(const float* dec_pose, const float* pose_gt, const float* bbox_gt, const float* fill_gt, const int64_t* class_gt,
+                          const float* moments, const float* prior, const int* prior_idx, int B, int NC, int L, int background_class_idx,
+                          int pose_loss_l2, int train_on_yaw, float gamma, float alpha, float* out, float* jac_pose, float* jac_mom,
+                          void* stream);
+int odvae_pose_losses_bwd_f32(const float* g, const float* jac_pose, const float* jac_mom, int B, int NC, float* d_dec_pose,
+                              float* d_moments, void* stream);
+
 /* ==== bf16 mixed-precision path (BASELINE.json configs[4]; reference knobs: configs/autoencoder/pose/autoencoder_kl_16x16x16.yaml:139
  * `precision`, train.py:521).  Activations bf16 NHWC in HBM, master weights / weight gradients / statistics f32, accumulation f32
  * on v_mfma_f32_32x32x16_bf16.  Every `void*` activation pointer below is bf16 unless the comment says otherwise. ================ */
