@@ -190,9 +190,15 @@ __global__ void wgrad_bf16_reduce_kernel(const float* __restrict__ slab, int spl
     const int co = (int)((idx / CinP) % CoutP);
     const int tap = (int)(idx / ((int64_t)CinP * CoutP));
     if (ci >= Cin || co >= Cout) continue;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * per + idx];
-    dw[((int64_t)co * Cin + ci) * taps + tap] = s;
+    // four independent partial sums: the loads of a thread are otherwise one dependent chain of `splits` L2 / HBM round trips
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += slab[(int64_t)k * per + idx]; s1 += slab[(int64_t)(k + 1) * per + idx];
+      s2 += slab[(int64_t)(k + 2) * per + idx]; s3 += slab[(int64_t)(k + 3) * per + idx];
+    }
+    for (; k < splits; ++k) s0 += slab[(int64_t)k * per + idx];
+    dw[((int64_t)co * Cin + ci) * taps + tap] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -224,7 +230,7 @@ bool make_plan(int mode, int N, int Ho, int Wo, int Cin, int Cout, Plan& pl) {
   if (nt >= (1ll << 31)) return false;
   pl.ntiles = (int)nt;
   const int pairs = (pl.CoutP / (pl.cot * 32)) * (pl.CinP / (pl.cit * 32));
-  int s = std::max(1, 512 / pairs);
+  int s = std::max(1, 256 / pairs);       // one 8-wave block per CU in a single round; fewer slabs for the reduce to read
   pl.splits = (int)std::min<int64_t>(s, nt);
   return true;
 }
@@ -281,7 +287,7 @@ int odvae_conv_wgrad_bf16(int mode, const void* x, const void* dy, int N, int Hi
   ODVAE_LAUNCH_CHECK("conv_wgrad_bf16");
   const int taps = mode == 4 ? 1 : 9;
   const int64_t per = (int64_t)taps * pl.CoutP * pl.CinP;
-  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(per, 256), 2048)), dim3(256), 0, st,
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(per, 256), 4096)), dim3(256), 0, st,
                      p.slab, pl.splits, taps, Cout, Cin, pl.CoutP, pl.CinP, dw, p.bslab, db);
   ODVAE_LAUNCH_CHECK("conv_wgrad_bf16 reduce");
   return ODVAE_OK;
