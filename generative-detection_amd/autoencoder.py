@@ -340,7 +340,7 @@ class PoseAutoencoder(AutoencoderKL):
         return out.to(self.device)
 
     def _perturbed_pose_forward(self, posterior_obj, dec_pose, batch, sample_posterior=True):
-        z_obj = posterior_obj.sample() if sample_posterior else posterior_obj.mode()
+        z_obj = posterior_obj.sample(self._noise("posterior_eps_perturbed")) if sample_posterior else posterior_obj.mode()
         enc_pose = self._encode_pose(self._perturb_poses(batch, dec_pose))
         return self.decode(ops.latent_combine(z_obj, None, enc_pose))
 

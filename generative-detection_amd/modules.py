@@ -236,10 +236,20 @@ class Decoder(nn.Module):
         h = self.conv_in(z)
         recompute = self.activation_checkpoint and torch.is_grad_enabled() and h.requires_grad
         run = (lambda f, t: torch.utils.checkpoint.checkpoint(f, t, use_reentrant=False)) if recompute else (lambda f, t: f(t))
-        h = run(lambda t: self.mid.block_2(self.mid.attn_1(self.mid.block_1(t))), h)
+        # With the fused (bf16) attention an AttnBlock keeps only qkv, o and one f32 per row for its backward, so it stays OUTSIDE
+        # the recomputed units: re-running the T x T products would cost far more than those tensors (3 of 8 attention forwards
+        # per step at configs[4]).  The f32 path materialises P ([N, T, T]) and keeps attention inside the unit.
+        attn_outside = recompute and self.compute_dtype == torch.bfloat16
+        if attn_outside:
+            h = run(self.mid.block_2, self.mid.attn_1(run(self.mid.block_1, h)))
+        else:
+            h = run(lambda t: self.mid.block_2(self.mid.attn_1(self.mid.block_1(t))), h)
         for level in reversed(range(self.num_resolutions)):
             stage = self.up[level]
             for i, block in enumerate(stage.block):
+                if len(stage.attn) > 0 and attn_outside:
+                    h = stage.attn[i](run(block, h))
+                    continue
                 unit = (lambda t, b=block, a=stage.attn[i]: a(b(t))) if len(stage.attn) > 0 else block
                 h = run(unit, h)
             if level != 0:

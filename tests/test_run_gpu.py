@@ -49,3 +49,35 @@ def test_log_images_matches_oracle_decode(hip_lib):
     rec = out["reconstructions_rgb"].cpu()
     assert (rec - dec_obj).abs().max().item() <= 1e-3 * max(1.0, dec_obj.abs().max().item())
     assert tuple(out["perturbed_pose_reconstruction_rgb"].shape) == (2, 3, 64, 64)
+
+
+def test_perturbed_pose_reconstruction_matches_oracle(hip_lib):
+    """log_images' second image (src/models/autoencoder.py:379-432): a fresh posterior sample, the decoded pose with its yaw
+    replaced by `yaw_perturbed`, pose-encoded and added to z, decoded -- against the same arithmetic on the oracle's modules."""
+    from odvae_amd import synthetic
+    from oracle.autoencoder import PoseAutoencoder as OraclePA
+    torch.manual_seed(4)
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32)
+    mcfg, _ = synthetic.model_config(YAML, latent_hw=4, ch=32)
+    p = mcfg.params.to_container()
+    ref = OraclePA(p["ddconfig"], dict(p["lossconfig"]["params"]), p["embed_dim"], p["pose_decoder_config"]["params"],
+                   p["pose_encoder_config"]["params"], feat_dims=p["feat_dims"], dropout_prob_final=p["dropout_prob_final"],
+                   dropout_warmup_steps=p["dropout_warmup_steps"],
+                   pose_conditioned_generation_steps=p["pose_conditioned_generation_steps"])
+    ref.load_state_dict(model.state_dict())
+    model = model.to("cuda:0").eval(); ref.eval()
+    batch = synthetic.make_batch(2, 64, seed=11)
+    noise = synthetic.make_noise(2, 4, seed=12)
+    noise["posterior_eps_perturbed"] = torch.randn(2, 16, 4, 4, generator=torch.Generator().manual_seed(13))
+    model.injected_noise = noise
+    out = model.log_images({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    x = ref._rescale(batch["patch"].float())
+    with torch.no_grad():
+        _, dec_pose, post, _ = ref.forward(x, noise, training=False)
+        z = post.sample(noise["posterior_eps_perturbed"])
+        pose = dec_pose.clone()
+        pose[:, 3] = batch["yaw_perturbed"]          # train_on_yaw: only the yaw slot is perturbed (:284-293,379-386)
+        want = ref.decode(z + ref.pose_encoder(pose).view(-1, *ref.feature_dims))
+    got = out["perturbed_pose_reconstruction_rgb"].cpu()
+    assert (got - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
+    assert (got - out["reconstructions_rgb"].cpu()).abs().max().item() > 1e-3      # it really is a different image
