@@ -53,6 +53,14 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
   return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so with the plain order the
+// eight neighbours of a tile run on eight different L2s and every halo / weight line is fetched once per XCD.  This bijection
+// gives XCD k the k-th contiguous eighth of the tile range (MI355X_MICROARCH.md, workgroup dispatch; cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -35,6 +35,7 @@ struct WinoParams {
   const float* residual;  // [N][H][W][Cout] or null
   float* y;               // [N][H][W][Cout]
   int N, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, act;
+  int xcd;                // 1: XCD-contiguous tile order (neighbouring tiles share an L2)
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xr = wave & 3, half = wave >> 2;          // row of the 4x4, co half
   const int li = lane & 31, h = lane >> 5;
-  int t = blockIdx.x;
+  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
@@ -505,6 +506,7 @@ int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const f
   ODVAE_CHECK_ARG((int64_t)H * W * Cin * 4 < 0x7FFFFFF0ll && (int64_t)H * W * Cout * 4 < 0x7FFFFFF0ll,
                   "conv3x3_wino: one input / output image must stay below 2 GiB");
   WinoParams p;
+  p.xcd = 0;
   p.x = x; p.upk = upk; p.bias = bias; p.residual = residual; p.y = y;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.CinP = odvae_conv3x3_wino_reduce_pad(Cin); p.CoutP = odvae_conv3x3_wino_out_pad(Cout);
@@ -519,6 +521,8 @@ int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const f
       odvae_set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return ODVAE_ERR_HIP;
     }
+    static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
+    p.xcd = xcd ? 1 : 0;
     hipLaunchKernelGGL(conv3x3_wino8_kernel, dim3((unsigned)sp, p.CoutP / BN8), dim3(512), smem, static_cast<hipStream_t>(stream), p);
   } else {
     hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(256), 0, static_cast<hipStream_t>(stream), p);

@@ -30,6 +30,7 @@ struct ConvB {
   void* y;                 // [N][Ho][Wo][Cout] bf16 (out_f32 = 0) or f32
   int N, Hi, Wi, Cin, Ho, Wo, Cout, CinP, CoutP;
   int tiles_x, tiles_y, out_f32;
+  int xcd;                 // 1: XCD-contiguous tile order
 };
 
 template <int MODE, int TH> struct HaloB;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvB p) {
   const int wco = wave / WAVES_PX, wpx = wave % WAVES_PX;
   const int li = lane & 31, h = lane >> 5;
 
-  int t = blockIdx.x;
+  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
   const int oy0 = ty * TH, ox0 = tx * TW;
@@ -351,6 +352,8 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.CinP = odvae_conv_bf16_reduce_pad(Cin); p.CoutP = odvae_conv_bf16_out_pad(Cout);
   p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, 8); p.out_f32 = out_f32;
+  static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
+  p.xcd = xcd ? 1 : 0;
   ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool k64 = p.CinP % 64 == 0;

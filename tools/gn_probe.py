@@ -1,4 +1,5 @@
-"""GroupNorm + swish forward / backward timing on one tensor shape (f32 or bf16).  usage: python tools/gn_probe.py [f32|bf16] [N C H iters]"""
+"""GroupNorm + swish forward / backward timing on one tensor shape (f32 or bf16); also served the Infinity-Cache sub-batching
+experiment recorded in DESIGN.md 7 (rejected).  usage: python tools/gn_probe.py [f32|bf16] [N C H iters]"""
 import os
 import sys
 import torch
@@ -24,6 +25,5 @@ for i in range(iters + 1):
     if i:
         tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
 nb = x.numel() * x.element_size()
-print("GN+swish %s N%d C%d %dx%d (%.0f MB/tensor, group budget %s MB): fwd %.3f ms = %.2f TB/s of 2 passes | bwd %.3f ms = %.2f TB/s of 4 passes"
-      % (sys.argv[1] if len(sys.argv) > 1 else "f32", N, C, H, H, nb / 1e6, os.environ.get("ODVAE_GN_GROUP_MB", "200"),
-         tf / iters, 2 * nb / (tf / iters) / 1e9, tb / iters, 4 * nb / (tb / iters) / 1e9))
+print("GN+swish %s N%d C%d %dx%d (%.0f MB/tensor): fwd %.3f ms = %.2f TB/s of 2 algorithmic passes | bwd (incl. folded skip gradient) %.3f ms = %.2f TB/s of 4 passes"
+      % (sys.argv[1] if len(sys.argv) > 1 else "f32", N, C, H, H, nb / 1e6, tf / iters, 2 * nb / (tf / iters) / 1e9, tb / iters, 4 * nb / (tb / iters) / 1e9))
