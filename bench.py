@@ -281,11 +281,11 @@ def main():
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
             tfile = None
-            for cand in ("r02_conv3x3_traffic.json", "r01_conv3x3_traffic.json"):
+            for cand in (("r02_bf16_conv_traffic.json",) if args.bf16 else ("r02_conv3x3_traffic.json", "r01_conv3x3_traffic.json")):
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     tfile = cand
                     break
-            if tfile and not args.gan and args.batch == 32 and args.res == 256 and not args.ckpt_decoder and not args.bf16:
+            if tfile and not args.gan and args.batch == 32 and args.res == 256 and not args.ckpt_decoder:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["hbm_bytes_per_launch"]
             wino = ops.WINOGRAD and not args.bf16
             ratio = 16.0 / 36.0 if wino else 1.0      # Winograd F(2x2,3x3) issues 16 of the direct form's 36 multiply-adds
