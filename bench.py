@@ -47,6 +47,8 @@ def parse():
                     help="CPU rehearsal of the N-rank launch path: ranks rendezvous over gloo, count themselves and run the "
                          "bucketed reducer on host tensors; no HIP kernel runs and the printed line is marked as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short side measurements (configs[4] in bf16, the headline shape in bf16) the default run appends")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
 
@@ -90,6 +92,44 @@ def cpu_baseline(res, batch=1, steps=1):
     dt = time.time() - t0
     return {"value": batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d step(s), B=%d, %dx%d, fp32, rec+KL only, torch %s CPU oracle" % (steps, batch, res, res, torch.__version__)}
+
+
+def side_run(dev, res, batch, steps, warmup, ckpt, precision):
+    """A second, smaller measurement in the same process (one GPU): images/s of another BASELINE.json configuration, no kernel
+    events.  Returns the dict that goes under `other_configs` of the one JSON line, or the error text -- it never fails the
+    headline."""
+    from odvae_amd import synthetic
+    from odvae_amd.trainer import Trainer
+    try:
+        torch.manual_seed(23)
+        lat = res // 16
+        model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat).to(dev).train()
+        model.decoder.activation_checkpoint = bool(ckpt)
+        model._global_step = 1
+        trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), precision=precision)
+        data = synthetic.make_batch(batch, res, seed=23)
+        data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+
+        def step(i):
+            b = dict(data)
+            b["pose_6d"] = data["pose_6d"].clone()
+            return trainer.training_batch(b, i)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                "dtype": "bf16" if str(precision) == "bf16" else "f32", "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+                "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, z=%dx%dx16, B=%d/GPU, rec+KL only%s, %s"
+                           % (res, res, lat, lat, batch, ", activation-checkpointed Decoder" if ckpt else "",
+                              "bf16 mixed precision" if str(precision) == "bf16" else "fp32")}}
+    except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def launch_ranks(args):
@@ -338,6 +378,19 @@ def main():
                 out["roofline_others"].append(e)
         out["peak_device_memory_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
         print("[bench] GPU leg done: %.2f images/s, %.1f ms/step" % (out["value"], ms), file=sys.stderr, flush=True)
+        default_cfg = not (args.gan or args.bf16 or args.ckpt_decoder) and args.res == 256 and args.batch == 32
+        if world == 1 and default_cfg and not args.no_other_configs:
+            # the other measured configurations of BASELINE.json, appended for the record (the headline above is untouched:
+            # its model is released first, the side runs carry no events)
+            del trainer, model
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = {
+                "configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder": side_run(dev, 512, 32, 4, 2, True, "bf16"),
+                "configs[1] shape (256x256, B=32) in bf16 mixed precision": side_run(dev, 256, 32, 10, 3, False, "bf16"),
+            }
+            print("[bench] side runs done", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.res, batch=2 if args.res <= 256 else 1, steps=2 if args.res <= 256 else 1)   # 10-30 s of host work
             # BASELINE.json configs[0] beside it: the reference's own CPU-runnable case (64x64, B=2, 10 steps)
