@@ -73,6 +73,9 @@ PROTOTYPES = {
     "odvae_lpips_distance_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_pose_losses_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "odvae_pose_losses_bwd_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "odvae_linear_workspace_bytes": (_Z, [_I, _I, _I]),
+    "odvae_linear_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "odvae_linear_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     # bf16 mixed-precision path
     "odvae_conv_bf16_reduce_pad": (_I, [_I]),
     "odvae_conv_bf16_out_pad": (_I, [_I]),

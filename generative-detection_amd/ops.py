@@ -1254,3 +1254,56 @@ class _PoseLosses(Function):
 
 def pose_losses(dec_pose, moments, pose_gt, bbox_gt, fill_gt, class_gt, prior, prior_idx, bg_idx=1, l2=False, yaw=True, gamma=2.0, alpha=0.25):
     return _PoseLosses.apply(dec_pose, moments, pose_gt, bbox_gt, fill_gt, class_gt, prior, prior_idx, bg_idx, l2, yaw, gamma, alpha)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pose head MLPs: skinny dense layers (linear_f32.hip)
+# ------------------------------------------------------------------------------------------------------
+LINEAR_ACTS = {None: 0, "none": 0, "tanh": 1, "swish": 2, "silu": 2, "relu": 3}
+
+
+class _LinearAct(Function):
+    """y = act(x . W^T + b) for the batch-sized rows of the pose MLPs (pose_encoder.py:59-131, pose_decoder.py:60-97); the
+    epilogue kernel fuses the split-K sum, the bias and the activation and keeps the pre-activation for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        L = _L()
+        x2 = x.detach().to(torch.float32).reshape(-1, x.shape[-1]).contiguous()
+        w = weight.detach().contiguous()
+        b = None if bias is None else bias.detach().contiguous()
+        _lib.require_device(x2, w, *(() if b is None else (b,)))
+        m, k = x2.shape
+        n = w.shape[0]
+        if w.shape[1] != k or (b is not None and b.numel() != n):
+            raise ValueError("linear_act: x %s, weight %s, bias %s" % (tuple(x.shape), tuple(w.shape), None if b is None else tuple(b.shape)))
+        y = torch.empty(m, n, dtype=torch.float32, device=x2.device)
+        pre = torch.empty_like(y) if act else None
+        wp, wn = _ws(L.odvae_linear_workspace_bytes(m, n, k), y)
+        _lib.check(L.odvae_linear_fwd_f32(x2.data_ptr(), w.data_ptr(), _lib.ptr(b), m, n, k, act, y.data_ptr(), _lib.ptr(pre), wp, wn,
+                                          _lib.stream_ptr()), "linear_fwd")
+        ctx.save_for_backward(x2, w, pre)
+        ctx.act, ctx.has_bias, ctx.x_shape = act, b is not None, x.shape
+        return y.reshape(x.shape[:-1] + (n,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _L()
+        x2, w, pre = ctx.saved_tensors
+        m, k = x2.shape
+        n = w.shape[0]
+        dy = dy.to(torch.float32).reshape(m, n).contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dpre = torch.empty_like(dy)
+        dx = torch.empty(m, k, dtype=torch.float32, device=dy.device) if need_x else None
+        dw = torch.empty(n, k, dtype=torch.float32, device=dy.device) if need_w else None
+        wp, wn = _ws(L.odvae_linear_workspace_bytes(m, n, k), dy)
+        _lib.check(L.odvae_linear_bwd_f32(x2.data_ptr(), w.data_ptr(), _lib.ptr(pre), dy.data_ptr(), m, n, k, ctx.act, dpre.data_ptr(),
+                                          _lib.ptr(dx), _lib.ptr(dw), wp, wn, _lib.stream_ptr()), "linear_bwd")
+        db = _colsum(dpre, m, n) if need_b else None
+        return (dx.reshape(ctx.x_shape) if need_x else None), dw, db, None
+
+
+def linear_act(x, weight, bias=None, act=None):
+    """act(x @ weight.T + bias) on the small-batch MFMA kernel; act in LINEAR_ACTS."""
+    return _LinearAct.apply(x, weight, bias, LINEAR_ACTS[act])

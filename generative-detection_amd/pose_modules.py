@@ -1,11 +1,36 @@
 """Pose head MLPs (spatial-VAE style), interface- and state_dict-compatible with
 src/modules/autoencodermodules/pose_encoder.py:59-131 (PoseEncoderSpatialVAE; legacy PoseEncoder :14-57) and
 src/modules/autoencodermodules/pose_decoder.py:60-97 (PoseDecoderSpatialVAE; legacy PoseDecoder :12-57).
-< 0.1 % of the step's FLOPs: they stay on torch.nn.Linear (hipBLASLt on ROCm), SURVEY.md 8(a) row a23.
+The nn.Linear modules only hold the parameters (state_dict keys as upstream); on the device every dense layer runs on
+ops.linear_act (csrc/linear_f32.hip: split-K 32 x 32 MFMA tiles, bias + activation fused in the reduce), SURVEY.md 8(a) row a23.
+Host tensors (the CPU-side interface tests) take torch's own path.
 """
 import numpy as np
 import torch
 import torch.nn as nn
+
+from . import ops
+
+_FUSABLE = {nn.Tanh: "tanh", nn.SiLU: "swish", nn.ReLU: "relu"}
+
+
+def _run_layers(seq, x):
+    """nn.Sequential of Linear / activation modules: on the device each Linear (+ the activation behind it) is one
+    ops.linear_act call; anything else (Softplus of the legacy heads) runs as the module it is."""
+    if not x.is_cuda:
+        return seq(x)
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            act = _FUSABLE.get(type(mods[i + 1])) if i + 1 < len(mods) else None
+            x = ops.linear_act(x, m.weight, m.bias, act)
+            i += 2 if act else 1
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 POSE_DIM = 4
 LHW_DIM = 3
@@ -34,7 +59,7 @@ class PoseEncoder(nn.Module):
         self.fc = _mlp3(pose_feat_dims, enc_feat_dims // 8, enc_feat_dims // 4, enc_feat_dims, activation)
 
     def forward(self, x):
-        return self.fc(x)
+        return _run_layers(self.fc, x)
 
 
 class PoseDecoder(nn.Module):
@@ -45,7 +70,7 @@ class PoseDecoder(nn.Module):
         self.fc = _mlp3(enc_feat_dims, enc_feat_dims // 4, enc_feat_dims // 8, pose_feat_dims, activation)
 
     def forward(self, x):
-        return self.fc(x)
+        return _run_layers(self.fc, x)
 
 
 class PoseEncoderSpatialVAE(nn.Module):
@@ -80,11 +105,16 @@ class PoseEncoderSpatialVAE(nn.Module):
         if z.dim() < 2:
             z = z.unsqueeze(0)
         b = z.size(0)
-        grid = self.x.to(z).expand(b, self.num_coords, self.in_dim).reshape(b, self.x_dim)
-        h = self.coord_linear(grid)
-        h_z = self.latent_linear(z)                                     # b x feat_size
+        if z.is_cuda:
+            # the grid is the same for every row: one row of coord_linear, broadcast over the batch
+            h = ops.linear_act(self.x.to(z).reshape(1, self.x_dim), self.coord_linear.weight, self.coord_linear.bias)
+            h_z = ops.linear_act(z, self.latent_linear.weight)
+        else:
+            grid = self.x.to(z).expand(b, self.num_coords, self.in_dim).reshape(b, self.x_dim)
+            h = self.coord_linear(grid)
+            h_z = self.latent_linear(z)                                 # b x feat_size
         h = h + h_z.unsqueeze(1).expand(b, self.num_coords, self.feat_size).reshape(b, self.h_dim)
-        return self.layers(h)
+        return _run_layers(self.layers, h)
 
 
 class PoseDecoderSpatialVAE(nn.Module):
@@ -106,4 +136,4 @@ class PoseDecoderSpatialVAE(nn.Module):
         self.layers = nn.Sequential(*seq)
 
     def forward(self, x):
-        return self.layers(x)
+        return _run_layers(self.layers, x)

@@ -210,6 +210,15 @@ int odvae_pose_losses_f32(const float* dec_pose, const float* pose_gt, const flo
 int odvae_pose_losses_bwd_f32(const float* g, const float* jac_pose, const float* jac_mom, int B, int NC, float* d_dec_pose,
                               float* d_moments, void* stream);
 
+/* ---- linear_f32.hip: small-batch dense layers of the pose-head MLPs (pose_encoder.py:59-131, pose_decoder.py:60-97) ------------ */
+size_t odvae_linear_workspace_bytes(int M, int N, int K);
+/* y [M][N] = act(x [M][K] . w [N][K]^T + bias); act 0 none | 1 tanh | 2 swish | 3 relu; pre (optional) = the pre-activation */
+int odvae_linear_fwd_f32(const float* x, const float* w, const float* bias, int M, int N, int K, int act, float* y, float* pre,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* dpre [M][N] = dy * act'(pre); dx [M][K] = dpre . w (or NULL); dw [N][K] = dpre^T . x (or NULL); bias gradient = column sum of dpre */
+int odvae_linear_bwd_f32(const float* x, const float* w, const float* pre, const float* dy, int M, int N, int K, int act, float* dpre,
+                         float* dx, float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ==== bf16 mixed-precision path (BASELINE.json configs[4]; reference knobs: configs/autoencoder/pose/autoencoder_kl_16x16x16.yaml:139
  * `precision`, train.py:521).  Activations bf16 NHWC in HBM, master weights / weight gradients / statistics f32, accumulation f32
  * on v_mfma_f32_32x32x16_bf16.  Every `void*` activation pointer below is bf16 unless the comment says otherwise. ================ */
