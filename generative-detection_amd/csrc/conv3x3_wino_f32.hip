@@ -275,9 +275,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   auto store_halo = [&](float* Hd) { store_halo_from(Hd, hreg); };
   auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
   auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
-  // thread = (tile, channel quad, row pair rp, column pair cp): rows {2rp, 2rp+1} x columns {2cp, 2cp+1} of V
+  // thread = (tile, channel quad, row pair rp, column pair cp): rows {2rp, 2rp+1} x columns {2cp, 2cp+1} of V.  (rp, cp) is
+  // wave-uniform (wave & 3): the four variants of the transform are scalar branches, so a wave executes only its own variant
+  // (with per-lane roles both sides of every branch ran: twice the vector instructions).
   auto transform = [&](const float* Hc, float* Vd) {
-    const int tile = tid >> 4, q = (tid >> 2) & 3, rp = (tid >> 1) & 1, cp = tid & 1;
+    const int idx = ((wave >> 2) << 6) | lane;
+    const int tile = idx >> 2, q = idx & 3, rp = (wave >> 1) & 1, cp = wave & 1;
     const int ty2 = 2 * (tile / TXN), tx2 = 2 * (tile % TXN);
     float4 ra[3], rb[3];   // rows of B^T d at patch columns cp, cp+1, cp+2
 #pragma unroll
@@ -308,15 +311,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
 
-  const float4* uq = reinterpret_cast<const float4*>(p.upk);
+  // Weight fragments come through a buffer descriptor: the lane part of the address (k half h, output channel) is one VGPR
+  // computed here, the (xi, chunk, group) part is a scalar offset and the second co-tile an immediate, so a fetch costs no
+  // vector instruction (64-bit per-lane address arithmetic was 13 % of the loop's issue cycles).
   const int QT = p.CinP / 4;
   const int nchunks = p.CinP / KC;
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.upk), 0, 16 * p.CinP * p.CoutP * 4, 0x00020000);
+  const unsigned b_voff = (unsigned)((h * p.CoutP + n0 + li) * 16);
+  const unsigned b_row = (unsigned)p.CoutP * 16u;      // bytes per k quad
   auto load_b = [&](int ch, int g, float4 (&b)[4][2]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t base = ((int64_t)(xr * 4 + j) * QT + ch * (KC / 4) + 2 * g + h) * p.CoutP + n0 + li;
-      b[j][0] = uq[base];
-      b[j][1] = uq[base + 32];
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((xr * 4 + j) * QT + ch * (KC / 4) + 2 * g) * (int)b_row);
+      const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, b_voff, soff, 0);
+      const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(ursrc, b_voff + 512u, soff, 0);
+      b[j][0] = make_float4(__uint_as_float(v0.x), __uint_as_float(v0.y), __uint_as_float(v0.z), __uint_as_float(v0.w));
+      b[j][1] = make_float4(__uint_as_float(v1.x), __uint_as_float(v1.y), __uint_as_float(v1.z), __uint_as_float(v1.w));
     }
   };
   auto load_a = [&](const float* Vc, int g, float4 (&a)[4]) {
@@ -335,13 +345,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
       }
   };
 
-  // vmcnt retires in order: whatever is waited on makes every OLDER load wait too.  The halo fetch (HBM latency) is
-  // therefore always the YOUNGEST load in flight when something else is awaited: per iteration the order of issue is
-  // b0(next chunk) in the middle, then at the end b1(next chunk) and last the halo of chunk ch+3, which is first
-  // awaited a whole iteration later (store_halo at the end of iteration ch+1).
-  // one set of weight fragments: the loads of the next group are issued right behind the MFMAs that read the current
-  // ones (64 registers less than double-buffering them: no scratch spills; the other wave of the SIMD covers the latency).
-  // No sched_barrier pins here: hipcc's own interleaving of the transform with the MFMAs measured 2-3 % faster.
+  // What the loop is built around (tools/mfma_mix_probe.hip, profiles/r02_wino8_loop.md): on gfx950 the f32 MFMA does not
+  // overlap other vector work -- every VALU instruction, and the register write-back of every LDS / memory load, takes its
+  // cycles away from the matrix pipe (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this kernel).  Latency is not the limiter (pinning
+  // the weight refills 24 MFMAs ahead, staggering the SIMD partners by half a chunk, dropping the barrier: no change each),
+  // instruction count is.  Hence: weight fetches with scalar offsets (no per-lane address arithmetic), wave-uniform
+  // transform roles, one set of weight registers refilled in place.
+  // vmcnt retires in order, so the halo fetch (HBM latency) is always the YOUNGEST load in flight when weights are awaited.
   float4 b[4][2], a[4];
   {   // prologue: the halos of chunks 0 and 1 are requested together (one HBM latency, not two in a row)
     float4 h1[HALO_IT];
@@ -355,15 +365,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   __syncthreads();
   transform(Hs, Vs);
   __syncthreads();
+  // pins the order {8 MFMAs of xi row j, the two weight fetches that refill b[j] for the next group} x 4: every fragment is
+  // re-requested as soon as its last MFMA has issued, 24 MFMAs before it is needed again
+  auto pin_reload = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+  };
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* Vc = Vs + (ch & 1) * V_F;
     load_a(Vc, 0, a);
     mma(a, b);
     load_b(ch, 1, b);
+    pin_reload();
     if (ch + 1 < nchunks) transform(Hs + ((ch + 1) & 1) * HALO_F, Vs + ((ch + 1) & 1) * V_F);
     load_a(Vc, 1, a);
     mma(a, b);
-    if (ch + 1 < nchunks) load_b(ch + 1, 0, b);
+    load_b(min(ch + 1, nchunks - 1), 0, b);     // past the last chunk: a harmless repeat keeps the block branch-free
+    pin_reload();
     if (ch + 2 < nchunks) store_halo(Hs + (ch & 1) * HALO_F);   // chunk ch+2; this stage was last read by transform(ch)
     if (ch + 3 < nchunks) load_halo((ch + 3) * KC);
     __syncthreads();
