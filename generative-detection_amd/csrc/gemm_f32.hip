@@ -40,24 +40,59 @@ struct GemmParams {
   const float* rowsub; const float* emul; int64_t sRow;
 };
 
+// Operand tiles are fetched through a buffer descriptor that starts at the tile's origin (first row of the block, first k of
+// the split): the per-lane byte offsets are computed once, a step only changes a scalar offset, and rows / k beyond the
+// operand fall past num_records and read as zero -- no per-step vector address arithmetic or compares (on gfx950 every
+// vector instruction takes its cycles from the f32 MFMA, profiles/r02_wino8_loop.md).
 template <bool KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int row0, int nrows,
-                                          int k0, int kend, float4 (&r)[4]) {
-  const int tid = threadIdx.x;
+struct TileFetch {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[4];
+  unsigned step_bytes;     // scalar advance per BK
+  int kvalid;              // KC only: k values of this split that exist (tail masking when not a multiple of BK)
+
+  // G: operand of this batch; rows [row0, nrows) x k [kbeg, kend) is what the block may touch
+  __device__ __forceinline__ void init(const float* G, int ld, int row0, int nrows, int kbeg, int kend) {
+    const int tid = threadIdx.x;
+    const unsigned OOB = 0x7FFFFFF0u;
+    kvalid = kend - kbeg;
+    if (KC) {            // G[row][k]: rows past nrows start beyond the last valid byte
+      const int rows = min(BM, nrows - row0);
+      const int64_t bytes = ((int64_t)(rows - 1) * ld + kvalid) * 4;
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + (int64_t)row0 * ld + kbeg, 0, (int)(bytes < 0x7FFFFFF0ll ? bytes : 0x7FFFFFF0ll), 0x00020000);
+      step_bytes = BK * 4u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int f = tid + 256 * i;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
-      const int row = row0 + (f >> 3), k = k0 + 4 * (f & 7);
-      if (row < nrows && k < kend) v = *reinterpret_cast<const float4*>(G + (int64_t)row * ld + k);
-    } else {
-      const int k = k0 + (f >> 5), row = row0 + 4 * (f & 31);
-      if (k < kend && row < nrows) v = *reinterpret_cast<const float4*>(G + (int64_t)k * ld + row);
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        voff[i] = (unsigned)(((f >> 3) * ld + 4 * (f & 7)) * 4);
+      }
+    } else {             // G[k][row]: k past kend starts beyond the last valid byte; rows are masked per lane
+      const int64_t bytes = ((int64_t)(kvalid - 1) * ld + (nrows - row0)) * 4;
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + (int64_t)kbeg * ld + row0, 0, (int)(bytes < 0x7FFFFFF0ll ? bytes : 0x7FFFFFF0ll), 0x00020000);
+      step_bytes = (unsigned)(BK * ld) * 4u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        voff[i] = (row0 + 4 * (f & 31) < nrows) ? (unsigned)(((f >> 5) * ld + 4 * (f & 31)) * 4) : OOB;
+      }
     }
-    r[i] = v;
   }
-}
+  // tile of step `step` (k = kbeg + step * BK ...)
+  __device__ __forceinline__ void load(int step, float4 (&r)[4]) const {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(step) * step_bytes;
+    const bool tail = KC && (step + 1) * BK > kvalid;      // uniform; only the last step of an odd-sized K
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned vo = voff[i];
+      if (tail) {
+        const int f = threadIdx.x + 256 * i;
+        if (step * BK + 4 * (f & 7) >= kvalid) vo = 0x7FFFFFF0u;
+      }
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, soff, 0);
+      r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  }
+};
 
 template <bool KC>
 __device__ __forceinline__ void store_tile(float* S, const float4 (&r)[4]) {
@@ -155,19 +190,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
   }
 
   float4 ra[4], rb[4];
+  TileFetch<A_KC> fa;
+  TileFetch<B_KC> fb;
   if (kbeg < kend) {
-    load_tile<A_KC>(A, p.lda, m0, p.M, kbeg, kend, ra);
-    load_tile<B_KC>(B, p.ldb, n0, p.N, kbeg, kend, rb);
+    fa.init(A, p.lda, m0, p.M, kbeg, kend);
+    fb.init(B, p.ldb, n0, p.N, kbeg, kend);
+    fa.load(0, ra);
+    fb.load(0, rb);
     store_tile<A_KC>(As, ra);
     store_tile<B_KC>(Bs, rb);
   }
   __syncthreads();
 
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  int step = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK, ++step) {
     const bool has_next = (k0 + BK) < kend;
     if (has_next) {
-      load_tile<A_KC>(A, p.lda, m0, p.M, k0 + BK, kend, ra);
-      load_tile<B_KC>(B, p.ldb, n0, p.N, k0 + BK, kend, rb);
+      fa.load(step + 1, ra);
+      fb.load(step + 1, rb);
     }
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
@@ -312,6 +352,10 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(p.tiles_m * ceil_div(N, BN), p.splits, batch), block(256);
   const bool a_kc = !transA, b_kc = transB != 0;
+  // 32-bit byte offsets inside one block's operand window (128 rows x the split's k range)
+  ODVAE_CHECK_ARG((a_kc ? (int64_t)BM * lda : (int64_t)p.k_per_split * lda) * 4 < 0x7FFFFFF0ll &&
+                  (b_kc ? (int64_t)BN * ldb : (int64_t)p.k_per_split * ldb) * 4 < 0x7FFFFFF0ll,
+                  "gemm_f32: one block's operand window exceeds 2 GiB (lda=%d ldb=%d K per split=%d)", lda, ldb, p.k_per_split);
   if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, p);
   else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, p);
   else if (!a_kc && b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, p);

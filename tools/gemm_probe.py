@@ -1,10 +1,13 @@
 """GEMM timings at the attention / 1x1 shapes of the step (B = 32)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from odvae_amd import ops
+from odvae_amd import ops, lib as _lib
+if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/bin/, not shipped)
+    _lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
 
-def timeit(fn, iters=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, iters=30):
+    for _ in range(15): fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): fn()
