@@ -13,7 +13,7 @@
 // row r of B^T d needs two of the four patch rows, row r of A dY one or both tile rows -- no transform work is repeated
 // across the four row blocks.  Per chunk of 16 tiles every thread fetches one (tile, channel quad) of x and of dy
 // straight from HBM into registers (a wavefront reads whole 512-byte channel rows), transforms it and writes V and dM
-// `[c][tile][128 + 4]` into LDS (double-buffered, 132 KB); the MFMA phase reads scalar fragments (lane = channel, the
+// `[c][tile][128]` into LDS (double-buffered, 128 KB); the MFMA phase reads scalar fragments (lane = channel, the
 // two k lanes = two tiles): 64 MFMAs per wave and barrier.  The fetch of chunk k+2 is in flight during the MFMAs of
 // chunk k.  Each block writes its partial dU slab; the reduction sums the slabs in a fixed order (deterministic),
 // applies G^T . G and writes OIHW.  The bias gradient rides along: dM[xi = (1,1)] is the sum of the tile's four dy pixels.
@@ -23,8 +23,9 @@
 namespace {
 
 constexpr int CT = 16;               // tiles per chunk
-constexpr int RS = 128 + 4;          // LDS row stride in floats ([c][tile][channel])
-constexpr int OPF = 4 * CT * RS;     // floats per operand and stage (8 448)
+constexpr int RS = 128;              // LDS row stride in floats ([c][tile][channel]); unpadded: every fragment offset is a multiple of 256 bytes, so
+                                     // the reads are ds_read2st64_b32 off three base registers with no per-read address arithmetic
+constexpr int OPF = 4 * CT * RS;     // floats per operand and stage (8 192)
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 struct WgwParams {
@@ -36,30 +37,36 @@ struct WgwParams {
 __device__ __forceinline__ float4 f4(u32x4 v) {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ float4 f4lin(float a, float4 x, float b, float4 y) {
-  return make_float4(a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z, a * x.w + b * y.w);
+// A * x + B * y with A, B in {-1, 0, 1} known at compile time: an add, a subtract, a negation or a copy
+template <int A, int B>
+__device__ __forceinline__ float4 f4lin(float4 x, float4 y) {
+  static_assert(A >= -1 && A <= 1 && B >= -1 && B <= 1 && (A != 0 || B != 0), "coefficients are -1, 0 or 1");
+  if constexpr (B == 0) return A > 0 ? x : make_float4(-x.x, -x.y, -x.z, -x.w);
+  else if constexpr (A == 0) return B > 0 ? y : make_float4(-y.x, -y.y, -y.z, -y.w);
+  else if constexpr (A > 0 && B > 0) return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  else if constexpr (A > 0) return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+  else if constexpr (B > 0) return make_float4(y.x - x.x, y.y - x.y, y.z - x.z, y.w - x.w);
+  else return make_float4(-x.x - y.x, -x.y - y.y, -x.z - y.z, -x.w - y.w);
 }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-template <bool WIDE>   // WIDE: a tile row holds at least CT tiles, the per-chunk tile advance needs no division
-__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p) {
-  extern __shared__ __attribute__((aligned(16))) float dsm[];   // stage s: V at s*2*OPF, dM at s*2*OPF + OPF
+// WIDE: a tile row holds at least CT tiles, the per-chunk tile advance needs no division.  R = the block's row of the 4x4
+// domain as a compile-time constant: the +-1 / 0 coefficients of its two transforms fold into adds, subtracts and nothing
+// (with run-time coefficients the staging was 24 multiplies + 16 fused multiply-adds per chunk and thread; on gfx950 vector
+// work is not hidden under the f32 MFMA, profiles/r02_wino8_loop.md).
+template <bool WIDE, int R>
+__device__ __forceinline__ void wgw_body(const WgwParams& p, float* dsm, const int split) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cig = wave & 3, coh = wave >> 2;
   const int li = lane & 31, h = lane >> 5;
-  // the four row blocks of one tile split read the same x / dy: linear block ids go round-robin over the 8 XCDs, so
-  // ids bx, bx + 8, bx + 16, bx + 24 (one XCD, one L2) take the four rows of one split when the split count allows it
-  const int bx = blockIdx.x;
-  const bool xcd_map = (p.nsplit & 7) == 0;
-  const int r = xcd_map ? (bx >> 3) & 3 : bx & 3;
-  const int split = xcd_map ? (bx & 7) + 8 * (bx >> 5) : bx >> 2;
+  constexpr int r = R;
   const int cib = blockIdx.y, cob = blockIdx.z;
   // row r of B^T d = sa * d[ra] + sb * d[rb];  row r of A dY = ya * dy[0] + yb * dy[1]
-  const int ra = r == 0 ? 0 : 1, rb = r == 3 ? 3 : 2;
-  const float sa = r == 2 ? -1.f : 1.f, sb = (r == 0 || r == 3) ? -1.f : 1.f;
-  const float ya = r == 3 ? 0.f : 1.f, yb = r == 0 ? 0.f : (r == 1 ? 1.f : -1.f);
+  constexpr int ra = r == 0 ? 0 : 1, rb = r == 3 ? 3 : 2;
+  constexpr int sa = r == 2 ? -1 : 1, sb = (r == 0 || r == 3) ? -1 : 1;
+  constexpr int ya = r == 3 ? 0 : 1, yb = r == 0 ? 0 : (r == 1 ? 1 : -1);
 
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x), 0, (unsigned)((int64_t)p.N * p.H * p.W * p.Cin * 4), 0x00020000);
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
 #endif
     const unsigned yo0 = (unsigned)((tn * p.H + 2 * tty) * p.W + 2 * ttx) * cout4 + chy;
     const unsigned yo1 = yo0 + (unsigned)p.W * cout4;
-    const bool u0 = valid && ya != 0.f, u1 = valid && yb != 0.f;
+    const bool u0 = valid && ya != 0, u1 = valid && yb != 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       yr[0][j] = f4(__builtin_amdgcn_raw_buffer_load_b128(yrsrc, u0 ? yo0 + j * cout4 : OOB, 0, 0));
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
   auto stage_x = [&](float* V) {
     float4 w[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) w[c] = f4lin(sa, xr[0][c], sb, xr[1][c]);
+    for (int c = 0; c < 4; ++c) w[c] = f4lin<sa, sb>(xr[0][c], xr[1][c]);
     float* vd = V + st * RS + 4 * sq;
     *reinterpret_cast<float4*>(vd + 0 * CT * RS) = f4sub(w[0], w[2]);
     *reinterpret_cast<float4*>(vd + 1 * CT * RS) = f4add(w[1], w[2]);
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
     *reinterpret_cast<float4*>(vd + 3 * CT * RS) = f4sub(w[1], w[3]);
   };
   auto stage_y = [&](float* M) {
-    const float4 z0 = f4lin(ya, yr[0][0], yb, yr[1][0]), z1 = f4lin(ya, yr[0][1], yb, yr[1][1]);
+    const float4 z0 = f4lin<ya, yb>(yr[0][0], yr[1][0]), z1 = f4lin<ya, yb>(yr[0][1], yr[1][1]);
     const float4 m1 = f4add(z0, z1);
     float* md = M + st * RS + 4 * sq;
     *reinterpret_cast<float4*>(md + 0 * CT * RS) = z0;
@@ -158,12 +165,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
 
   // fragments of k step t2 (tiles 2 t2, 2 t2 + 1) into set s; eight MFMAs per step
   float fa[2][4], fb[2][4][2];
+  // The second co-tile is read through its own base register (its +32 is hidden from the compiler): otherwise hipcc pairs the
+  // two co-tiles of one (c, k step) in a ds_read2_b32 and spends a v_add on a fresh base for every one of the 32 pairs.
+  int nt1 = 32;
+  asm volatile("" : "+v"(nt1));
   auto ldf = [&](const float* va, const float* mb, int t2, int s) {
+    const float* mb1 = mb + nt1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       fa[s][c] = va[(c * CT + 2 * t2) * RS];
       fb[s][c][0] = mb[(c * CT + 2 * t2) * RS];
-      fb[s][c][1] = mb[(c * CT + 2 * t2) * RS + 32];
+      fb[s][c][1] = mb1[(c * CT + 2 * t2) * RS];
     }
   };
   auto mm = [&](int s) {
@@ -236,6 +248,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p)
       for (int t = 0; t < CT; ++t) s += dsm[t * 128 + tid];
       p.bias_part[(int64_t)split * p.Cout + cob * 128 + tid] = s;
     }
+  }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_wino_kernel(WgwParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // stage s: V at s*2*OPF, dM at s*2*OPF + OPF
+  // the four row blocks of one tile split read the same x / dy: linear block ids go round-robin over the 8 XCDs, so
+  // ids bx, bx + 8, bx + 16, bx + 24 (one XCD, one L2) take the four rows of one split when the split count allows it
+  const int bx = blockIdx.x;
+  const bool xcd_map = (p.nsplit & 7) == 0;
+  const int r = xcd_map ? (bx >> 3) & 3 : bx & 3;
+  const int split = xcd_map ? (bx & 7) + 8 * (bx >> 5) : bx >> 2;
+  switch (r) {      // block-uniform
+    case 0: wgw_body<WIDE, 0>(p, dsm, split); break;
+    case 1: wgw_body<WIDE, 1>(p, dsm, split); break;
+    case 2: wgw_body<WIDE, 2>(p, dsm, split); break;
+    default: wgw_body<WIDE, 3>(p, dsm, split); break;
   }
 }
 

@@ -54,12 +54,13 @@ def time_():
         x = torch.randn(b, h, h, cin, device=dev)
         dy = torch.randn(b, h, h, cout, device=dev)
         for kind in ("direct", "wino"):
-            run(kind, x, dy, cin, cout); torch.cuda.synchronize()
+            for _ in range(30): run(kind, x, dy, cin, cout)      # clock ramp
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5): run(kind, x, dy, cin, cout)
+            for _ in range(40): run(kind, x, dy, cin, cout)
             e1.record(); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
+            ms = e0.elapsed_time(e1) / 40
             gf = 2.0 * 9 * cin * cout * b * h * h / 1e9
             print("B%d %d->%d @%d %-6s %.3f ms  %.1f TFLOP/s (direct-form FLOPs)" % (b, cin, cout, h, kind, ms, gf / ms), flush=True)
         a, _ = run("direct", x, dy, cin, cout); c, _ = run("wino", x, dy, cin, cout); torch.cuda.synchronize()
