@@ -89,6 +89,16 @@ __device__ __forceinline__ void wgw_body(const WgwParams& p, float* dsm, const i
   }
   const unsigned cin4 = (unsigned)p.Cin * 4u, cout4 = (unsigned)p.Cout * 4u;
   const unsigned chx = (unsigned)(cib * 128 + 4 * sq) * 4u, chy = (unsigned)(cob * 128 + 4 * sq) * 4u;
+  // byte offsets of this thread's patch origin (input row 2 tty - 1, column 2 ttx - 1: may "be negative", the masks below
+  // cover exactly those lanes) and of its dy tile; unsigned arithmetic, consistent modulo 2^32
+  unsigned xoff, yoff;
+  const unsigned step_x = 2u * CT * cin4, step_x_wrap = step_x + (unsigned)p.W * cin4;
+  const unsigned step_y = 2u * CT * cout4, step_y_wrap = step_y + (unsigned)p.W * cout4;
+  auto set_bases = [&]() {
+    xoff = (unsigned)((tn * p.H + 2 * tty - 1) * p.W + 2 * ttx - 1) * cin4 + chx;
+    yoff = (unsigned)((tn * p.H + 2 * tty) * p.W + 2 * ttx) * cout4 + chy;
+  };
+  set_bases();
   float4 xr[2][4], yr[2][2];
   auto fetch_x = [&]() {
 #ifdef ODVAE_WGW_NOFETCH   // ablation build: every fetch is answered with zeros by the descriptor, no memory traffic
@@ -96,11 +106,9 @@ __device__ __forceinline__ void wgw_body(const WgwParams& p, float* dsm, const i
 #else
     const bool valid = tl < end_tile;
 #endif
-    const int prow = tn * p.H + 2 * tty - 1;                     // input row of patch row 0 (may be -1: masked below)
     const bool rok0 = valid && (ra != 0 || tty > 0), rok1 = valid && (rb != 3 || tty < p.TY - 1);
     const bool cok0 = ttx > 0, cok3 = ttx < p.TX - 1;
-    const unsigned xo0 = (unsigned)((prow + ra) * p.W + 2 * ttx - 1) * cin4 + chx;
-    const unsigned xo1 = (unsigned)((prow + rb) * p.W + 2 * ttx - 1) * cin4 + chx;
+    const unsigned xo0 = xoff + (unsigned)(ra * p.W) * cin4, xo1 = xoff + (unsigned)(rb * p.W) * cin4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bool cok = c == 0 ? cok0 : (c == 3 ? cok3 : true);
@@ -114,8 +122,7 @@ __device__ __forceinline__ void wgw_body(const WgwParams& p, float* dsm, const i
 #else
     const bool valid = tl < end_tile;
 #endif
-    const unsigned yo0 = (unsigned)((tn * p.H + 2 * tty) * p.W + 2 * ttx) * cout4 + chy;
-    const unsigned yo1 = yo0 + (unsigned)p.W * cout4;
+    const unsigned yo0 = yoff, yo1 = yoff + (unsigned)p.W * cout4;
     const bool u0 = valid && ya != 0, u1 = valid && yb != 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -124,13 +131,21 @@ __device__ __forceinline__ void wgw_body(const WgwParams& p, float* dsm, const i
     }
     tl += CT;
     if constexpr (WIDE) {
-      ttx += CT;
-      if (ttx >= p.TX) { ttx -= p.TX; tty += 1; if (tty >= p.TY) { tty = 0; tn += 1; } }
+      // W = 2 TX and H = 2 TY: a step of CT tiles moves the patch by 2 CT pixels, plus one pixel row when the tile row wraps
+      // (tile rows of consecutive images are consecutive), so the offsets advance by adds -- no multiplies per chunk
+      const int nx = ttx + CT;
+      const bool wrap = nx >= p.TX;
+      xoff += wrap ? step_x_wrap : step_x;
+      yoff += wrap ? step_y_wrap : step_y;
+      ttx = wrap ? nx - p.TX : nx;
+      const int ny = tty + (wrap ? 1 : 0);
+      tty = ny >= p.TY ? 0 : ny;        // tn itself is only needed by the non-WIDE path
     } else {
       const int per_img = p.TY * p.TX;
       tn = tl / per_img;
       const int rem = tl - tn * per_img;
       tty = rem / p.TX; ttx = rem - tty * p.TX;
+      set_bases();
     }
   };
   float4 bias_acc = make_float4(0.f, 0.f, 0.f, 0.f);
