@@ -411,17 +411,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
     const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
     unsigned off[4][2][2];
     float seed[4][2][2];      // bias + residual (a descriptor of 0 bytes returns 0 when there is no residual)
+    // register r = 4 xr + rr of this wave is tile (rr + 4h) of tile row xr: output pixel (oy0 + 2 xr, ox0 + 8h + 2 rr) and its
+    // three neighbours.  One multiply for the wave's first pixel, the other 15 offsets are adds of scalar steps; H and W are
+    // even, so a 2x2 output tile is inside the image or outside as a whole (the launcher keeps OOB - steps >= num_records).
+    const unsigned cstep = (unsigned)p.Cout * 4u, rstep = (unsigned)(p.W * p.Cout) * 4u;
+    const unsigned oob = 0x7FFFFFF0u - rstep - cstep;
+    const int py = oy0 + 2 * xr, px0 = ox0 + 8 * h;
+    const unsigned base0 = (unsigned)(((py * p.W + px0) * p.Cout + co) * 4);
+    const bool rowok = py < p.H && co < p.Cout;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int r = xr * 4 + rr;
-      const int tile = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int py = oy0 + 2 * (tile / TXN), px = ox0 + 2 * (tile % TXN);
+      const unsigned b0 = (rowok && px0 + 2 * rr < p.W) ? base0 + 2u * rr * cstep : oob;
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
-          const int oy = py + a2, ox = px + c;
-          off[rr][c][a2] = (oy < p.H && ox < p.W && co < p.Cout) ? (unsigned)(((oy * p.W + ox) * p.Cout + co) * 4) : 0x7FFFFFF0u;
+          off[rr][c][a2] = b0 + c * cstep + a2 * rstep;
           seed[rr][c][a2] = bv + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, off[rr][c][a2], 0, 0));
         }
     }
@@ -524,7 +529,7 @@ int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const f
   ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino: empty shape");
   ODVAE_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cin % 4 == 0, "conv3x3_wino: needs even H, W and Cin %% 4 == 0 (H=%d W=%d Cin=%d)", H, W, Cin);
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)upk & 15) == 0, "conv3x3_wino: x/upk must be 16-byte aligned");
-  ODVAE_CHECK_ARG((int64_t)H * W * Cin * 4 < 0x7FFFFFF0ll && (int64_t)H * W * Cout * 4 < 0x7FFFFFF0ll,
+  ODVAE_CHECK_ARG((int64_t)H * W * Cin * 4 < 0x7FFFFFF0ll && ((int64_t)(H + 1) * W + 1) * Cout * 4 < 0x7FFFFFF0ll,
                   "conv3x3_wino: one input / output image must stay below 2 GiB");
   WinoParams p;
   p.xcd = 0;
