@@ -231,8 +231,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoParams p) {
 // transform is done once per 128 output channels instead of once per 64.  111 KB of LDS: one block per CU.
 constexpr int BN8 = 128;
 
+// PERSIST: one block per CU walks a sequence of tiles and the chunk pipeline runs on across the tile boundary -- the halo
+// fetches, halo stores and the first transform of the next tile take the slots the last three chunks of the current tile
+// leave empty, and its first weight fragments are requested behind the last MFMAs.  The next tile then starts with its first
+// MFMA: no prologue (fetch -> LDS -> transform -> LDS, 5.5k of a block's 95k cycles with nothing to overlap) except for a
+// block's first tile.  Needs an even chunk count >= 4 (the two-stage rotation of halo and V then continues seamlessly) and
+// the output exchange in LDS that the next tile's staged data does not use (X behind the second V stage: 135 KB in all).
+constexpr int X_OFF_PERSIST = 2 * HALO_F + V_F;
+
+template <bool PERSIST>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
-  extern __shared__ __attribute__((aligned(16))) float dsmem[];   // 2 halo stages + 2 V stages
+  extern __shared__ __attribute__((aligned(16))) float dsmem[];   // 2 halo stages + 2 V stages (+ the exchange area when PERSIST)
   float* Hs = dsmem;
   float* Vs = dsmem + 2 * HALO_F;
 
@@ -240,27 +249,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xr = wave & 3, half = wave >> 2;          // row of the 4x4, co half
   const int li = lane & 31, h = lane >> 5;
-  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int n0 = blockIdx.y * BN8 + half * 64;
-  const float* xn = p.x + (int64_t)n * p.H * p.W * p.Cin;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, p.H * p.W * p.Cin * 4, 0x00020000);
+  // Tile sequence of this block.  Not PERSIST: the one tile blockIdx.x names.  PERSIST (1-D grid of G blocks, G % (8 ny) == 0):
+  // block b works on co block (b >> 3) % ny and on tiles i_b, i_b + TL, i_b + 2 TL, ... of the XCD-contiguous order, where
+  // TL = G / ny blocks share a co block and i_b % 8 == b % 8, the XCD the block runs on.
+  const int total_tiles = p.tiles_x * p.tiles_y * p.N;
+  const int ny = p.CoutP / BN8;
+  const int TL = PERSIST ? (int)gridDim.x / ny : 0;
+  const int yblk = PERSIST ? ((int)blockIdx.x >> 3) % ny : (int)blockIdx.y;
+  int s_cur = PERSIST ? ((int)blockIdx.x & 7) + 8 * (((int)blockIdx.x >> 3) / ny) : (int)blockIdx.x;
+  struct Tile { int oy0, ox0, n; __amdgpu_buffer_rsrc_t xrsrc; };
+  auto decode = [&](int sidx) {
+    int t = (PERSIST || p.xcd) ? xcd_contiguous(sidx, PERSIST ? total_tiles : (int)gridDim.x) : sidx;
+    Tile T;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; T.n = t / p.tiles_y;
+    T.oy0 = ty * TH; T.ox0 = tx * TW;
+    T.xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)T.n * p.H * p.W * p.Cin), 0, p.H * p.W * p.Cin * 4, 0x00020000);
+    return T;
+  };
+  Tile cur = decode(s_cur);
+  const int n0 = yblk * BN8 + half * 64;
 
   constexpr int HALO_F4 = HH * HW * (KC / 4);           // 720
   constexpr int HALO_IT = (HALO_F4 + 511) / 512;        // 2
   float4 hreg[HALO_IT];
-  auto load_halo_to = [&](int c0, float4 (&hr)[HALO_IT]) {
+  auto load_halo_to = [&](const Tile& T, int c0, float4 (&hr)[HALO_IT]) {
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
       const int f = tid + 512 * i;
       const int hp = f >> 2, q = f & 3;
-      const int iy = oy0 - 1 + hp / HW, ix = ox0 - 1 + hp % HW;
+      const int iy = T.oy0 - 1 + hp / HW, ix = T.ox0 - 1 + hp % HW;
       const int c = c0 + 4 * q;
       const bool ok = f < HALO_F4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
       const unsigned voff = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + c) * 4) : 0x7FFFFFF0u;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(T.xrsrc, voff, 0, 0);
       hr[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
   };
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
       if (f < HALO_F4) *reinterpret_cast<float4*>(Hd + (f >> 2) * HS + 4 * (f & 3)) = hr[i];
     }
   };
-  auto load_halo = [&](int c0) { load_halo_to(c0, hreg); };
+  auto load_halo = [&](const Tile& T, int c0) { load_halo_to(T, c0, hreg); };
   auto store_halo = [&](float* Hd) { store_halo_from(Hd, hreg); };
   auto f4add = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
   auto f4sub = [](float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); };
@@ -304,12 +326,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   };
 
   f32x16 acc[4][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
 
   // Weight fragments come through a buffer descriptor: the lane part of the address (k half h, output channel) is one VGPR
   // computed here, the (xi, chunk, group) part is a scalar offset and the second co-tile an immediate, so a fetch costs no
@@ -355,12 +371,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
   float4 b[4][2], a[4];
   {   // prologue: the halos of chunks 0 and 1 are requested together (one HBM latency, not two in a row)
     float4 h1[HALO_IT];
-    load_halo(0);
-    if (nchunks > 1) load_halo_to(KC, h1);
+    load_halo(cur, 0);
+    if (nchunks > 1) load_halo_to(cur, KC, h1);
     load_b(0, 0, b);
     store_halo(Hs);
     if (nchunks > 1) store_halo_from(Hs + HALO_F, h1);
-    if (nchunks > 2) load_halo(2 * KC);
+    if (nchunks > 2) load_halo(cur, 2 * KC);
   }
   __syncthreads();
   transform(Hs, Vs);
@@ -374,27 +390,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
       __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     }
   };
+  for (;;) {      // tiles of this block (exactly one unless PERSIST)
+  const int s_nxt = s_cur + TL;
+  const bool has_next = PERSIST && s_nxt < total_tiles;
+  const Tile nxt = decode(has_next ? s_nxt : s_cur);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* Vc = Vs + (ch & 1) * V_F;
     load_a(Vc, 0, a);
     mma(a, b);
     load_b(ch, 1, b);
     pin_reload();
-    if (ch + 1 < nchunks) transform(Hs + ((ch + 1) & 1) * HALO_F, Vs + ((ch + 1) & 1) * V_F);
+    // chunk indices past the end of this tile are the first chunks of the next one (PERSIST: nchunks is even, the stage
+    // rotation carries over)
+    if (ch + 1 < nchunks || has_next) transform(Hs + ((ch + 1) & 1) * HALO_F, Vs + ((ch + 1) & 1) * V_F);
     load_a(Vc, 1, a);
     mma(a, b);
-    load_b(min(ch + 1, nchunks - 1), 0, b);     // past the last chunk: a harmless repeat keeps the block branch-free
+    load_b(ch + 1 < nchunks ? ch + 1 : 0, 0, b);     // past the last chunk: the next tile's first fragments (same co block)
     pin_reload();
-    if (ch + 2 < nchunks) store_halo(Hs + (ch & 1) * HALO_F);   // chunk ch+2; this stage was last read by transform(ch)
-    if (ch + 3 < nchunks) load_halo((ch + 3) * KC);
+    if (ch + 2 < nchunks || has_next) store_halo(Hs + (ch & 1) * HALO_F);   // chunk ch+2; this stage was last read by transform(ch)
+    if (ch + 3 < nchunks) load_halo(cur, (ch + 3) * KC);
+    else if (has_next) load_halo(nxt, (ch + 3 - nchunks) * KC);
     __syncthreads();
   }
 
   // output transform: as in the 4-wave kernel, one exchange area per co half: X[half][row][c][reg][lane].  The residual
   // values of this wave's 16 output elements are requested BEFORE the exchange barrier (their latency hides under it) and
   // the stores then follow with no load in between (vmcnt retires loads and stores in order).
-  float* X = dsmem + half * 8192;
+  float* X = dsmem + (PERSIST ? X_OFF_PERSIST : 0) + half * 8192;
   const int img_bytes = p.H * p.W * p.Cout * 4;
+  const int n = cur.n, oy0 = cur.oy0, ox0 = cur.ox0;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, p.residual ? img_bytes : 0, 0x00020000);
@@ -445,6 +475,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
     }
     __syncthreads();
   }
+  if (!has_next) break;
+  cur = nxt;
+  s_cur = s_nxt;
+  }      // tiles
 }
 
 // U[xi = 4a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles.
@@ -541,15 +575,21 @@ int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const f
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino: too many tiles");
   static const bool no8 = getenv("ODVAE_WINO_4WAVE") != nullptr;
   if (Cout % BN8 == 0 && !no8) {
-    const size_t smem = (size_t)(2 * HALO_F + 2 * V_F) * sizeof(float);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    // the persistent form needs >= 2 tiles per block, an even chunk count >= 4 and a grid that splits evenly over the co blocks
+    static const bool no_persist = getenv("ODVAE_WINO_PERSIST") != nullptr && atoi(getenv("ODVAE_WINO_PERSIST")) == 0;
+    const int ny = p.CoutP / BN8, nchunks = p.CinP / KC, G = 256;
+    const bool persist = !no_persist && nchunks >= 4 && (nchunks & 1) == 0 && G % (8 * ny) == 0 && sp >= 2 * (G / ny);
+    const size_t smem = (size_t)(persist ? X_OFF_PERSIST + 16384 : 2 * HALO_F + 2 * V_F) * sizeof(float);
+    auto kern = persist ? conv3x3_wino8_kernel<true> : conv3x3_wino8_kernel<false>;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
       odvae_set_error("conv3x3_wino: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return ODVAE_ERR_HIP;
     }
     static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
     p.xcd = xcd ? 1 : 0;
-    hipLaunchKernelGGL(conv3x3_wino8_kernel, dim3((unsigned)sp, p.CoutP / BN8), dim3(512), smem, static_cast<hipStream_t>(stream), p);
+    if (persist) hipLaunchKernelGGL(kern, dim3(G), dim3(512), smem, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)sp, ny), dim3(512), smem, static_cast<hipStream_t>(stream), p);
   } else {
     hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   }

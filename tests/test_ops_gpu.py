@@ -159,6 +159,36 @@ def test_winograd_and_direct_kernels_agree(hip_lib, monkeypatch):
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(4, 128, 128, 128, 128), (5, 64, 128, 112, 160), (3, 128, 256, 64, 96), (2, 64, 512, 64, 128)])
+def test_winograd_persistent_form(hip_lib, monkeypatch, n, cin, cout, h, w):
+    """Layers with at least two tiles per block run the persistent form of the Winograd kernel (the chunk pipeline carries on
+    across the tile boundary; conv3x3_wino_f32.hip): 512 / 700 / 288 / 256 tiles over 256 / 256 / 128 / 64 blocks per output-channel
+    block, i.e. even and uneven tile counts per block and one, two and four co blocks.  Forward (bias + residual) against torch on
+    the host, forward and data gradient against the direct kernel, and a bit-identical repeat."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, w, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g).to(dev())
+    ref = torch.nn.functional.conv2d(x, wt, b, padding=1) + res
+    outs = []
+    for wino in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD", wino)
+        xd = x.to(dev()).requires_grad_(True)
+        y = ops.conv3x3(xd, wt.to(dev()).requires_grad_(True), b.to(dev()), res.to(dev()))
+        y.backward(gy)
+        outs.append((y.detach(), xd.grad))
+    close(outs[0][0], ref, FWD_TOL, "persistent winograd fwd vs torch")
+    for a, d in zip(*outs):
+        assert (a - d).abs().max().item() <= 1e-5 * d.abs().max().item()
+    monkeypatch.setattr(ops, "WINOGRAD", True)
+    with torch.no_grad():
+        again = ops.conv3x3(x.to(dev()), wt.to(dev()), b.to(dev()), res.to(dev()))
+    assert torch.equal(again, outs[0][0])
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 128, 16, 16), (1, 128, 256, 8, 12), (3, 256, 128, 6, 10),
                                             (2, 128, 128, 2, 2), (1, 384, 128, 4, 34)])
 def test_winograd_domain_weight_gradient(hip_lib, n, cin, cout, h, w):

@@ -6,7 +6,8 @@ if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/bi
     _lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
 dev = "cuda:0"
 # correctness first (A/B builds are not covered by the test-suite): odd tile counts, a residual, several chunk counts
-for (b, cin, cout, h, wd) in [] if os.environ.get("WINO_NOCHECK") else [(1, 16, 128, 8, 16), (2, 32, 128, 10, 18), (1, 48, 128, 16, 16), (2, 128, 128, 64, 48), (1, 64, 256, 24, 40), (3, 256, 128, 16, 16), (1, 512, 512, 32, 32)]:
+for (b, cin, cout, h, wd) in [] if os.environ.get("WINO_NOCHECK") else [(1, 16, 128, 8, 16), (2, 32, 128, 10, 18), (1, 48, 128, 16, 16), (2, 128, 128, 64, 48), (1, 64, 256, 24, 40), (3, 256, 128, 16, 16), (1, 512, 512, 32, 32),
+                               (4, 128, 128, 128, 128), (2, 64, 256, 128, 128), (5, 128, 128, 112, 160), (3, 256, 512, 64, 96)]:   # the last four: several tiles per block (persistent form)
     x = torch.randn(b, h, wd, cin, device=dev).permute(0, 3, 1, 2)
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     bias = torch.randn(cout, device=dev)
