@@ -577,7 +577,12 @@ int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const f
   if (Cout % BN8 == 0 && !no8) {
     // the persistent form needs >= 2 tiles per block, an even chunk count >= 4 and a grid that splits evenly over the co blocks
     static const bool no_persist = getenv("ODVAE_WINO_PERSIST") != nullptr && atoi(getenv("ODVAE_WINO_PERSIST")) == 0;
-    const int ny = p.CoutP / BN8, nchunks = p.CinP / KC, G = 256;
+    static const int cus = [] {      // one persistent block per CU (256 on MI355X)
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const int ny = p.CoutP / BN8, nchunks = p.CinP / KC, G = cus;
     const bool persist = !no_persist && nchunks >= 4 && (nchunks & 1) == 0 && G % (8 * ny) == 0 && sp >= 2 * (G / ny);
     const size_t smem = (size_t)(persist ? X_OFF_PERSIST + 16384 : 2 * HALO_F + 2 * V_F) * sizeof(float);
     auto kern = persist ? conv3x3_wino8_kernel<true> : conv3x3_wino8_kernel<false>;
