@@ -14,7 +14,7 @@ for cfg in "f32:conv3x3_wino8_kernel:" "bf16:conv_bf16_kernel:--bf16"; do
   name=${cfg%%:*}; rest=${cfg#*:}; kern=${rest%%:*}; flag=${rest#*:}
   for ctr in FETCH_SIZE WRITE_SIZE; do
     out=/tmp/pmc_${name}_$ctr; rm -rf $out
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o p -- python3 $root/bench.py $flag --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2> /tmp/pmc_${name}_$ctr.err
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o p -- python3 $root/bench.py $flag --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-other-configs > /dev/null 2> /tmp/pmc_${name}_$ctr.err
   done
   python3 $root/tools/collect_traffic.py /tmp/pmc_${name}_FETCH_SIZE /tmp/pmc_${name}_WRITE_SIZE $root/gpurun_out/${tag}_${name}_conv_traffic.json $kern
   rm -rf /tmp/pmc_${name}_FETCH_SIZE /tmp/pmc_${name}_WRITE_SIZE
