@@ -118,7 +118,10 @@ __device__ __forceinline__ void read_frag(const float* S, int row, int g, int h,
 }
 
 template <bool A_KC, bool B_KC, bool SMB = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+// Three blocks per CU for the form with both operands k-contiguous (150 registers, the accumulators in VGPRs): QK^T-shaped and
+// 1x1-forward products gain 4-6 % from the third block covering prologue / store bursts; the k-strided forms and the split-K
+// weight-gradient shapes lose 3-10 % with it and stay at two (tools/gemm_probe.py).
+__global__ __launch_bounds__(256, (A_KC && B_KC && !SMB) ? 3 : 1) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
   float* As = smem;
   float* Bs = smem + TILE_FLOATS;
