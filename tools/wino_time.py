@@ -18,7 +18,7 @@ for (b, cin, cout, h, wd) in [] if os.environ.get("WINO_NOCHECK") else [(1, 16, 
     err = (y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
     print("check %dx%dx%dx%d->%d: max err / max|y| = %.2e %s" % (b, cin, h, wd, cout, err, "ok" if err < 2e-5 else "WRONG"), flush=True)
     assert err < 2e-5
-for (b, cin, cout, h) in [(32,128,128,256),(32,256,256,64)]:
+for (b, cin, cout, h) in ([(32,128,128,256)] if os.environ.get("WINO_ONLY_BIG") else [(32,128,128,256),(32,256,256,64)]):
     x = torch.randn(b, h, h, cin, device=dev).permute(0,3,1,2)
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     bias = torch.randn(cout, device=dev)
