@@ -117,11 +117,12 @@ __device__ __forceinline__ void read_frag(const float* S, int row, int g, int h,
   }
 }
 
-template <bool A_KC, bool B_KC, bool SMB = false>
-// Three blocks per CU for the form with both operands k-contiguous (150 registers, the accumulators in VGPRs): QK^T-shaped and
-// 1x1-forward products gain 4-6 % from the third block covering prologue / store bursts; the k-strided forms and the split-K
-// weight-gradient shapes lose 3-10 % with it and stay at two (tools/gemm_probe.py).
-__global__ __launch_bounds__(256, (A_KC && B_KC && !SMB) ? 3 : 1) void gemm_f32_kernel(GemmParams p) {
+template <bool A_KC, bool B_KC, bool SMB = false, bool OCC3 = (A_KC && B_KC && !SMB)>
+// OCC3: three blocks per CU (150 registers, the accumulators in VGPRs).  The form with both operands k-contiguous (QK^T-shaped
+// and 1x1-forward products) gains 4-6 % from the third block covering prologue / store bursts, the unsplit batched TN products
+// of the attention backward 3 %; the NN form and the split-K weight-gradient shapes lose 3-10 % with it and stay at two
+// (tools/gemm_probe.py).
+__global__ __launch_bounds__(256, OCC3 ? 3 : 1) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
   float* As = smem;
   float* Bs = smem + TILE_FLOATS;
@@ -362,6 +363,7 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, p);
   else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, p);
   else if (!a_kc && b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, p);
+  else if (p.splits == 1 && batch > 1) hipLaunchKernelGGL((gemm_f32_kernel<false, false, false, true>), grid, block, 0, st, p);
   else                     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, st, p);
   ODVAE_LAUNCH_CHECK("gemm_f32");
   if (p.splits > 1) {
