@@ -5,7 +5,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from odvae_amd import ops  # noqa: E402
+from odvae_amd import ops, lib as _lib  # noqa: E402
+if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/bin/, not shipped)
+    _lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
 
 which = sys.argv[1] if len(sys.argv) > 1 else "flash_fwd"
 N, C, H = (int(v) for v in (sys.argv[2:5] if len(sys.argv) > 4 else (8, 256, 64)))
