@@ -371,6 +371,15 @@ def main():
                               "frac": r["tbytes_per_s"] * 1e3 / PEAK_HBM_GBS,
                               "algorithmic_bytes_per_step": r["bytes_per_launch"] * r["launches"],
                               "note": "algorithmic bytes = x read + y written (forward), x, dy (, skip gradient) read + dx written (backward)"})
+                    fam = os.path.join(ROOT, "profiles", "r02_family_traffic.json")
+                    if not (args.gan or args.bf16 or args.ckpt_decoder) and args.res == 256 and args.batch == 32 and os.path.exists(fam):
+                        # HBM bytes the family actually moves (statistics / reduce are passes of their own), from the committed PMC
+                        # passes of this command (FETCH_SIZE x2 + WRITE_SIZE, two steps counted), over the time measured live here
+                        ks = json.load(open(fam))["kernels"]
+                        moved = sum((v["fetch_bytes_total_corrected"] + v["write_bytes_total"]) / 2.0 for k, v in ks.items() if k.startswith("gn_"))
+                        e.update({"traffic": moved, "traffic_unit": "HBM bytes per step (PMC, profiles/r02_family_traffic.json)",
+                                  "achieved_on_traffic": moved / (e["total_ms"] * 1e-3) / 1e9,
+                                  "frac_on_traffic": moved / (e["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS})
                 else:
                     k = 16.0 / 36.0 if key == "conv3x3_wgrad_wino" else 1.0
                     e.update({"bound": "mfma", "achieved": r["tflops"] * k, "peak": mfma_peak, "unit": "TFLOP/s",
