@@ -30,7 +30,7 @@ def _stale(target, deps):
 
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bf16_common.h"), os.path.abspath(__file__)]
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bf16_common.h"), os.path.join(CSRC, "gn_finalize.h"), os.path.abspath(__file__)]
     if _stale(obj, deps):
         cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -6,6 +6,8 @@
 
 namespace {
 
+#include "gn_finalize.h"
+
 struct GnB {
   int N, HW, C, G, cpg, octs, pix_per_pass, chunks, pix_per_chunk;
 };
@@ -66,22 +68,6 @@ __global__ __launch_bounds__(256) void gnb_stats_kernel(const bf16_t* __restrict
     float* o = partial + (((int64_t)n * s.chunks + chunk) * s.G + tid) * 2;
     o[0] = a; o[1] = b;
   }
-}
-
-__global__ void gnb_finalize_kernel(const float* __restrict__ partial, GnB s, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= s.N * s.G) return;
-  const int n = idx / s.G, g = idx % s.G;
-  double a = 0.0, b = 0.0;
-  for (int ch = 0; ch < s.chunks; ++ch) {
-    const float* o = partial + (((int64_t)n * s.chunks + ch) * s.G + g) * 2;
-    a += (double)o[0]; b += (double)o[1];
-  }
-  const double m = (double)s.HW * s.cpg, mu = a / m;
-  double var = b / m - mu * mu;
-  if (var < 0.0) var = 0.0;
-  mean[idx] = (float)mu;
-  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 struct Oct { float g[8], b[8], mu[8], rs[8], ds1[8], ds2[8]; };
@@ -159,39 +145,6 @@ __global__ __launch_bounds__(256) void gnb_bwd_reduce_kernel(const bf16_t* __res
     for (int ps = 0; ps < s.pix_per_pass; ++ps) { sa += red[0][ps * s.C + cc]; sb += red[1][ps * s.C + cc]; }
     o[cc] = sa; o[s.C + cc] = sb;
   }
-}
-
-__global__ void gnb_bwd_finalize_kernel(const float* __restrict__ partial, GnB s, const float* __restrict__ gamma,
-                                        float* __restrict__ chan, float* __restrict__ grp) {
-  extern __shared__ float sh[];  // [2][C]
-  const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
-    double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < s.chunks; ++ch) {
-      const float* o = partial + ((int64_t)n * s.chunks + ch) * 2 * s.C;
-      a += (double)o[c]; b += (double)o[s.C + c];
-    }
-    chan[((int64_t)n * 2 + 0) * s.C + c] = (float)a;
-    chan[((int64_t)n * 2 + 1) * s.C + c] = (float)b;
-    sh[c] = (float)(a * (double)gamma[c]);
-    sh[s.C + c] = (float)(b * (double)gamma[c]);
-  }
-  __syncthreads();
-  for (int g = threadIdx.x; g < s.G; g += blockDim.x) {
-    float a = 0.f, b = 0.f;
-    for (int j = 0; j < s.cpg; ++j) { a += sh[g * s.cpg + j]; b += sh[s.C + g * s.cpg + j]; }
-    grp[((int64_t)n * s.G + g) * 2 + 0] = a;
-    grp[((int64_t)n * s.G + g) * 2 + 1] = b;
-  }
-}
-
-__global__ void gnb_bwd_param_kernel(const float* __restrict__ chan, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int n = 0; n < N; ++n) { a += (double)chan[((int64_t)n * 2 + 0) * C + c]; b += (double)chan[((int64_t)n * 2 + 1) * C + c]; }
-  dgamma[c] = (float)a;
-  dbeta[c] = (float)b;
 }
 
 // dx = rstd * (du*gamma - (ds2 + xhat*ds1)/m) (+ the skip connection's gradient, folded in)
@@ -347,7 +300,7 @@ int odvae_groupnorm_fwd_bf16(const void* x, int N, int HW, int C, int G, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   hipLaunchKernelGGL(gnb_stats_kernel, dim3(s.chunks, N), dim3(256), 0, st, static_cast<const bf16_t*>(x), s, partial);
-  hipLaunchKernelGGL(gnb_finalize_kernel, dim3(ceil_div(N * G, 256)), dim3(256), 0, st, partial, s, eps, mean, rstd);
+  hipLaunchKernelGGL(gn_finalize_kernel<GnB>, dim3(ceil_div(N * G, 4)), dim3(256), 0, st, partial, s, eps, mean, rstd);
   hipLaunchKernelGGL(gnb_apply_kernel, dim3(apply_blocks(s), N), dim3(256), 0, st, static_cast<const bf16_t*>(x), s, gamma, beta, mean, rstd,
                      swish, static_cast<bf16_t*>(y));
   ODVAE_LAUNCH_CHECK("groupnorm_fwd_bf16");
@@ -375,8 +328,9 @@ int odvae_groupnorm_bwd_bf16(const void* x, const void* dy, int N, int HW, int C
   const bf16_t* xb = static_cast<const bf16_t*>(x);
   const bf16_t* db = static_cast<const bf16_t*>(dy);
   hipLaunchKernelGGL(gnb_bwd_reduce_kernel, dim3(s.chunks, N), dim3(256), 0, st, xb, db, s, gamma, beta, mean, rstd, swish, partial);
-  hipLaunchKernelGGL(gnb_bwd_finalize_kernel, dim3(N), dim3(256), 2 * C * sizeof(float), st, partial, s, gamma, chan, grp);
-  hipLaunchKernelGGL(gnb_bwd_param_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
+  if (s.cpg <= 64) hipLaunchKernelGGL(gn_bwd_finalize_kernel<GnB>, dim3(N, ceil_div(C, (64 / s.cpg) * s.cpg)), dim3(256), 0, st, partial, s, gamma, chan, grp);
+  else hipLaunchKernelGGL(gn_bwd_finalize_wide_kernel<GnB>, dim3(N), dim3(256), 2 * C * sizeof(float), st, partial, s, gamma, chan, grp);
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
   hipLaunchKernelGGL(gnb_bwd_apply_kernel, dim3(apply_blocks(s), N), dim3(256), 0, st, xb, db, s, gamma, beta, mean, rstd, grp, swish,
                      static_cast<const bf16_t*>(dx_add), static_cast<bf16_t*>(dx));
   ODVAE_LAUNCH_CHECK("groupnorm_bwd_bf16");

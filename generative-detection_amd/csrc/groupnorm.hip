@@ -13,6 +13,8 @@
 
 namespace {
 
+#include "gn_finalize.h"
+
 struct GnShape {
   int N, HW, C, G, cpg;      // cpg = C / G
   int quads;                 // C / 4
@@ -64,24 +66,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     float* o = partial + (((int64_t)n * s.chunks + chunk) * s.G + tid) * 2;
     o[0] = a; o[1] = b;
   }
-}
-
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, GnShape s, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= s.N * s.G) return;
-  const int n = idx / s.G, g = idx % s.G;
-  double a = 0.0, b = 0.0;
-  for (int ch = 0; ch < s.chunks; ++ch) {
-    const float* o = partial + (((int64_t)n * s.chunks + ch) * s.G + g) * 2;
-    a += (double)o[0]; b += (double)o[1];
-  }
-  const double m = (double)s.HW * s.cpg;
-  const double mu = a / m;
-  double var = b / m - mu * mu;
-  if (var < 0.0) var = 0.0;
-  mean[idx] = (float)mu;
-  rstd[idx] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // ---- forward apply -------------------------------------------------------------------------------
@@ -197,43 +181,6 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// per (n, c): A = sum du*xhat, B = sum du (f64 over chunks).  One block per sample, thread per channel.
-// Writes chan[n][2][C] and the per-group ds1 = sum_c gamma*A, ds2 = sum_c gamma*B into grp[n][G][2].
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, GnShape s, const float* __restrict__ gamma,
-                                       float* __restrict__ chan, float* __restrict__ grp) {
-  extern __shared__ float sh[];  // [2][C]
-  const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < s.C; c += blockDim.x) {
-    double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < s.chunks; ++ch) {
-      const float* o = partial + ((int64_t)n * s.chunks + ch) * 2 * s.C;
-      a += (double)o[c]; b += (double)o[s.C + c];
-    }
-    chan[((int64_t)n * 2 + 0) * s.C + c] = (float)a;
-    chan[((int64_t)n * 2 + 1) * s.C + c] = (float)b;
-    sh[c] = (float)(a * (double)gamma[c]);
-    sh[s.C + c] = (float)(b * (double)gamma[c]);
-  }
-  __syncthreads();
-  for (int g = threadIdx.x; g < s.G; g += blockDim.x) {
-    float a = 0.f, b = 0.f;
-    for (int j = 0; j < s.cpg; ++j) { a += sh[g * s.cpg + j]; b += sh[s.C + g * s.cpg + j]; }
-    grp[((int64_t)n * s.G + g) * 2 + 0] = a;
-    grp[((int64_t)n * s.G + g) * 2 + 1] = b;
-  }
-}
-
-// dgamma[c] = sum_n A[n][c], dbeta[c] = sum_n B[n][c]
-__global__ void gn_bwd_param_kernel(const float* __restrict__ chan, int N, int C,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int n = 0; n < N; ++n) { a += (double)chan[((int64_t)n * 2 + 0) * C + c]; b += (double)chan[((int64_t)n * 2 + 1) * C + c]; }
-  dgamma[c] = (float)a;
-  dbeta[c] = (float)b;
-}
-
 // dx = rstd * (du*gamma - (ds2 + xhat*ds1)/m); same launch shape as gn_apply_kernel
 template <bool SWISH>
 __device__ __forceinline__ float4 gn_bwd_quad(const float4 xv, const float4 dv, const GnQuad& k, float inv_m) {
@@ -332,7 +279,7 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
   float* partial = static_cast<float*>(workspace);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(s.chunks, N), dim3(256), 0, st, x, s, partial);
   ODVAE_LAUNCH_CHECK("groupnorm stats");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div(N * G, 256)), dim3(256), 0, st, partial, s, eps, mean, rstd);
+  hipLaunchKernelGGL(gn_finalize_kernel<GnShape>, dim3(ceil_div(N * G, 4)), dim3(256), 0, st, partial, s, eps, mean, rstd);
   ODVAE_LAUNCH_CHECK("groupnorm finalize");
   const dim3 grid(apply_blocks(s), N);
   if (swish) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
@@ -363,9 +310,10 @@ int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int 
   if (swish) hipLaunchKernelGGL((gn_bwd_reduce_kernel<true>), dim3(s.chunks, N), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, partial);
   else       hipLaunchKernelGGL((gn_bwd_reduce_kernel<false>), dim3(s.chunks, N), dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, partial);
   ODVAE_LAUNCH_CHECK("groupnorm bwd reduce");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 2 * C * sizeof(float), st, partial, s, gamma, chan, grp);
+  if (s.cpg <= 64) hipLaunchKernelGGL(gn_bwd_finalize_kernel<GnShape>, dim3(N, ceil_div(C, (64 / s.cpg) * s.cpg)), dim3(256), 0, st, partial, s, gamma, chan, grp);
+  else hipLaunchKernelGGL(gn_bwd_finalize_wide_kernel<GnShape>, dim3(N), dim3(256), 2 * C * sizeof(float), st, partial, s, gamma, chan, grp);
   ODVAE_LAUNCH_CHECK("groupnorm bwd finalize");
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
   ODVAE_LAUNCH_CHECK("groupnorm bwd param");
   const dim3 grid(apply_blocks(s), N);
   if (swish) hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx_add, dx);
