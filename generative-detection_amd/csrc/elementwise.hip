@@ -316,7 +316,36 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   // thread t handles column (t % C) for C <= 256 (several row lanes), else strides over columns
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = std::min<int64_t>(rows, r0 + rows_per_block);
-  if (C <= 256) {
+  if ((C & 3) == 0 && C <= 1024 && (((uintptr_t)x) & 15) == 0) {
+    // channel quads: thread = (quad, row lane); 16-byte loads, four rows in flight per thread (the scalar form below runs
+    // one dependent 4-byte load at a time: 2 TB/s on the 1x1 convolutions' 0.1-0.5 GB inputs)
+    __shared__ float4 sh4[256];
+    const int Q = C >> 2, lanes = 256 / Q;
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < lanes) {
+      const float4* xq = reinterpret_cast<const float4*>(x) + q;
+      int64_t r = r0 + rl;
+      for (; r + 3 * lanes < r1; r += 4 * lanes) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xq[(r + (int64_t)u * lanes) * Q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
+      }
+      for (; r < r1; r += lanes) { const float4 v = xq[r * Q]; acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w; }
+    }
+    sh4[threadIdx.x] = make_float4((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                                   (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
+    __syncthreads();
+    if (threadIdx.x < Q) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < lanes; ++k) { const float4 v = sh4[k * Q + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * C + 4 * threadIdx.x) = t;
+    }
+  } else if (C <= 256) {
     __shared__ float sh[256];
     const int lanes = 256 / C;
     const int c = threadIdx.x % C, rl = threadIdx.x / C;
