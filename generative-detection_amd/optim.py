@@ -73,21 +73,43 @@ class FusedAdam(torch.optim.Optimizer):
         f = self.materialize()
         return [(p, o, p.numel()) for p, o in zip(f["params"], f["offsets"])]
 
-    def _ensure_grad_views(self):
+    def gather_grads(self, indices=None):
+        """Bring the gradients of parameters `indices` (default: all) into the arena and re-point `.grad` at their arena views.
+        After `zero_grad(set_to_none=True)` autograd hands each parameter the tensor the weight-gradient kernel produced (no
+        accumulate kernel per parameter); those tensors are copied into the arena by ONE multi-tensor copy here, slices of
+        parameters the backward did not reach are zeroed (the norm kernel reads the whole arena).  Gradients that already live
+        in the arena are left alone."""
         f = self._flat
-        for p, o in zip(f["params"], f["offsets"]):
+        dst, src, zero = [], [], []
+        rng = range(len(f["params"])) if indices is None else indices
+        for i in rng:
+            p, o = f["params"][i], f["offsets"][i]
             want = f["g"][o:o + p.numel()]
             if p.grad is None:
-                want.zero_()          # parameter took no part in this backward
+                zero.append(want)
                 p.grad = want.view(p.shape)
             elif p.grad.data_ptr() != want.data_ptr():
-                want.copy_(p.grad.reshape(-1))  # someone replaced .grad (e.g. zero_grad(set_to_none=True) + backward)
-                p.grad = want.view(p.shape)
+                dst.append(want.view(p.shape))
+                src.append(p.grad)
+                p.grad = dst[-1]
+        with torch.no_grad():
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if zero:
+                torch._foreach_zero_(zero)
+
+    def _ensure_grad_views(self):
+        self.gather_grads()
 
     def zero_grad(self, set_to_none=False):
-        """Gradients stay views of the arena; zeroing is one memset."""
+        """set_to_none=False: gradients stay views of the arena, zeroing is one memset.  set_to_none=True (what the trainer
+        uses): `.grad` is dropped, the next backward's gradients are gathered into the arena by `gather_grads`."""
         if self._flat is None:
             return super().zero_grad(set_to_none=set_to_none)
+        if set_to_none:
+            for p in self._flat["params"]:
+                p.grad = None
+            return
         self._flat["g"].zero_()
         for p, o in zip(self._flat["params"], self._flat["offsets"]):
             if p.grad is None or p.grad.data_ptr() != self._flat["g"][o:o + 1].data_ptr():

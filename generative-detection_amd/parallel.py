@@ -54,8 +54,10 @@ class GradReducer:
                     self.param_bucket[m] = b
                 start, members = None, []
         self.bucket_size = [0] * len(self.buckets)
+        self.bucket_members = [[] for _ in self.buckets]      # parameter indices (arena order) per bucket
         for i in range(len(slices)):
             self.bucket_size[self.param_bucket[i]] += 1
+            self.bucket_members[self.param_bucket[i]].append(i)
         self._pending = None
         self._works = []
         self._launched = set()
@@ -68,10 +70,12 @@ class GradReducer:
     def prepare_for_backward(self):
         if self.own_arena:
             self.arena.zero_()
-        for p, off, n in self.slices:
-            view = self.arena[off:off + n].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                p.grad = view
+            for p, off, n in self.slices:
+                view = self.arena[off:off + n].view(p.shape)
+                if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                    p.grad = view
+        # FusedAdam's arena: `.grad` is whatever the trainer left (None after zero_grad(set_to_none=True)); a bucket's
+        # gradients are gathered into the arena right before its collective (`_launch`)
         self._pending = list(self.bucket_size)
         self._works = []
         self._launched = set()
@@ -89,6 +93,8 @@ class GradReducer:
 
     def _launch(self, b):
         s, e = self.buckets[b]
+        if not self.own_arena:
+            self.optimizer.gather_grads(self.bucket_members[b])
         self._launched.add(b)
         self.launch_order.append(b)
         self._works.append(dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -6,6 +6,8 @@ i.e. by 2 per batch (every `global_step` threshold in the model and the loss dep
 Launcher concerns of train.py (loggers, checkpoints callbacks, CLI) are out of scope; `fit` takes any iterable of
 batch dicts.
 """
+import os
+
 import torch
 
 from .parallel import GradReducer
@@ -69,7 +71,7 @@ class Trainer:
             saved = self._toggle(idx)
             try:
                 loss = model.training_step(batch, batch_idx, idx)
-                opt.zero_grad()
+                opt.zero_grad(set_to_none=True)   # FusedAdam: gradients are gathered into its arena after the backward (optim.gather_grads)
                 red = self.reducers[idx] if self.reducers else None
                 if red is not None:
                     red.prepare_for_backward()
