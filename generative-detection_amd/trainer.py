@@ -6,8 +6,6 @@ i.e. by 2 per batch (every `global_step` threshold in the model and the loss dep
 Launcher concerns of train.py (loggers, checkpoints callbacks, CLI) are out of scope; `fit` takes any iterable of
 batch dicts.
 """
-import os
-
 import torch
 
 from .parallel import GradReducer
