@@ -54,7 +54,9 @@ class FusedAdam(torch.optim.Optimizer):
                 g.copy_(p.grad)
             p.grad = g
         self._flat = dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p),
-                          offsets=offs, total=total, params=ps)
+                          offsets=offs, total=total, params=ps,
+                          gviews=[flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(ps, offs)],
+                          gptrs=[flat_g.data_ptr() + 4 * o for o in offs])
         self._clip = torch.ones(2, dtype=torch.float32, device=dev)
         # torch.optim.Adam keeps a step count per parameter and skips parameters without a gradient (e.g. the
         # decoder during encoder pre-training); hooks record which parameters a backward actually reached
@@ -80,18 +82,18 @@ class FusedAdam(torch.optim.Optimizer):
         parameters the backward did not reach are zeroed (the norm kernel reads the whole arena).  Gradients that already live
         in the arena are left alone."""
         f = self._flat
+        views, ptrs, params = f["gviews"], f["gptrs"], f["params"]      # cached: this loop runs once per step on the host
         dst, src, zero = [], [], []
-        rng = range(len(f["params"])) if indices is None else indices
-        for i in rng:
-            p, o = f["params"][i], f["offsets"][i]
-            want = f["g"][o:o + p.numel()]
-            if p.grad is None:
-                zero.append(want)
-                p.grad = want.view(p.shape)
-            elif p.grad.data_ptr() != want.data_ptr():
-                dst.append(want.view(p.shape))
-                src.append(p.grad)
-                p.grad = dst[-1]
+        for i in (range(len(params)) if indices is None else indices):
+            p = params[i]
+            g = p.grad
+            if g is None:
+                zero.append(views[i])
+                p.grad = views[i]
+            elif g.data_ptr() != ptrs[i]:
+                dst.append(views[i])
+                src.append(g)
+                p.grad = views[i]
         with torch.no_grad():
             if dst:
                 torch._foreach_copy_(dst, src)
