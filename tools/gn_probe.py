@@ -4,10 +4,12 @@ import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from odvae_amd import ops  # noqa: E402
+from odvae_amd import ops, lib as _lib  # noqa: E402
+if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/bin/, not shipped)
+    _lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
 dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
 N, C, H = (int(v) for v in (sys.argv[2:5] if len(sys.argv) > 4 else (32, 128, 256)))
-iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 40
 dev = torch.device("cuda:0")
 x = torch.randn(N, H, H, C, device=dev).to(dt).permute(0, 3, 1, 2).requires_grad_(True)
 g, b = torch.ones(C, device=dev, requires_grad=True), torch.zeros(C, device=dev, requires_grad=True)
