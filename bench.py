@@ -65,7 +65,7 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(res, batch=1, steps=1):
+def cpu_baseline(res, batch=1, steps=1, warmup=1):
     """Oracle (plain torch on the host cores) on a bounded sample of the same workload: same yaml, same step
     definition (fwd + bwd + clip + Adam), rec+KL only, at `res` x `res`, batch `batch`."""
     from odvae_amd import synthetic
@@ -86,12 +86,15 @@ def cpu_baseline(res, batch=1, steps=1):
     opts = ref.configure_optimizers()
     batch_d = synthetic.make_batch(batch, res, seed=23)
     noise = synthetic.make_noise(batch, lat, seed=24)
+    for _ in range(warmup):
+        train_batch(ref, opts, batch_d, {0: noise}, optimizer_indices=(0,), clip=1.0)
     t0 = time.time()
     for _ in range(steps):
         train_batch(ref, opts, batch_d, {0: noise}, optimizer_indices=(0,), clip=1.0)
     dt = time.time() - t0
     return {"value": batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d step(s), B=%d, %dx%d, fp32, rec+KL only, torch %s CPU oracle" % (steps, batch, res, res, torch.__version__)}
+            "sample": "%d warm-up + %d timed step(s), B=%d, %dx%d, fp32, rec+KL only, torch %s CPU oracle"
+                      % (warmup, steps, batch, res, res, torch.__version__)}
 
 
 def side_run(dev, res, batch, steps, warmup, ckpt, precision):
@@ -121,9 +124,11 @@ def side_run(dev, res, batch, steps, warmup, ckpt, precision):
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
+        host = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         return {"value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                "host_enqueue_ms_per_step": host / steps * 1e3, "host_over_gpu": host / dt,
                 "dtype": "bf16" if str(precision) == "bf16" else "f32", "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
                 "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, z=%dx%dx16, B=%d/GPU, rec+KL only%s, %s"
                            % (res, res, lat, lat, batch, ", activation-checkpointed Decoder" if ckpt else "",
@@ -272,9 +277,11 @@ def main():
         # overlapped.  Around every 0.8 ms f32 conv that costs 0.3 % of the step; around every 0.29 ms bf16 conv it cost 25 %
         # (200 vs 251 images/s).  In bf16 mode one launch in eight of the dominant family is bracketed (17 per step).
         ops.KERNEL_EVENTS.sample = 8 if args.bf16 else 1
+    sample = 8 if (args.bf16 and not args.no_kernel_events) else 1   # launches / share below are scaled back by it (estimates when > 1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    host_s = time.perf_counter() - t0      # the host has enqueued every launch of the timed steps; the GPU is still working
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -310,6 +317,8 @@ def main():
             "n_gpus": world, "ranks_joined": ranks_joined, "backend": "rccl" if use_dist else "none", "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+            # python + launch calls of one step, no synchronisation (rank 0): the step is host-bound when this approaches ms_per_step
+            "host_enqueue_ms_per_step": host_s / args.steps * 1e3, "host_over_gpu": host_s / elapsed,
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
                        % (args.res, args.res, args.batch,
                           ("PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
@@ -336,12 +345,13 @@ def main():
                                "kernel": ("conv_bf16_kernel (3x3 conv fwd + dgrad, all modes, bf16 implicit GEMM, 128 px x 128 co per block)" if args.bf16
                                           else "conv3x3_wino8_kernel (stride-1 3x3 conv fwd + dgrad, Winograd F(2x2,3x3), 32 tiles x 128 co per block)"
                                           if wino else "conv3x3_kernel_v2<MODE 0,KC 32,2,2,2,2> (3x3 conv fwd + dgrad, 128px x 128co tile)"),
-                               "launches": roof["launches"], "avg_launch_ms": roof["avg_ms"],
+                               "launches": roof["launches"] * sample, "timed_launches": roof["launches"], "sampled_1_in": sample,
+                               "avg_launch_ms": roof["avg_ms"],
                                "issued_gflop_per_launch": roof["gflop_per_launch"] * ratio,
                                "algorithmic_gflop_per_launch": roof["gflop_per_launch"],
                                "algorithmic_tflops": roof["tflops"],
                                "algorithmic_bytes_per_launch": roof["bytes_per_launch"],
-                               "share_of_step_time": roof["total_ms"] / (ms * args.steps),
+                               "share_of_step_time": roof["total_ms"] * sample / (ms * args.steps),
                                "note": ("achieved/frac price the multiply-adds actually ISSUED to the f32 MFMA pipe; "
                                         "algorithmic_tflops is the direct-convolution work (2*9*Cin*Cout per pixel, SURVEY.md 8(d)) "
                                         "the same launches deliver" + (", 36/16 of the issued work under Winograd" if wino else ""))}
@@ -401,9 +411,10 @@ def main():
             }
             print("[bench] side runs done", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.res, batch=2 if args.res <= 256 else 1, steps=2 if args.res <= 256 else 1)   # 10-30 s of host work
+            # one warm-up step, then >= 3 timed steps (B=2 at 256x256: ~4.5 s each on 16 cores)
+            out["cpu_baseline"] = cpu_baseline(args.res, batch=2 if args.res <= 256 else 1, steps=3 if args.res <= 256 else 1, warmup=1)
             # BASELINE.json configs[0] beside it: the reference's own CPU-runnable case (64x64, B=2, 10 steps)
-            out["cpu_baseline"]["config1"] = cpu_baseline(64, batch=2, steps=10)
+            out["cpu_baseline"]["config1"] = cpu_baseline(64, batch=2, steps=10, warmup=1)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -128,7 +128,8 @@ class _Vgg16Features(nn.Module):
 
 class NetLinLayer(nn.Module):
     """[UPSTREAM] lpips.NetLinLayer: Sequential(Dropout, Conv2d(chn_in, 1, 1, bias=False)) -> key lin{k}.model.1.weight.
-    The net is frozen in eval mode, so the Dropout is the identity; the 1x1 conv is folded into ops.lpips_layer_distance."""
+    The Dropout holds the key index; it never drops anything here: LPIPSStyle pins itself to eval mode (see its `train`), and
+    the 1x1 conv is folded into ops.lpips_layer_distance."""
 
     def __init__(self, chn_in, chn_out=1, use_dropout=True):
         super().__init__()
@@ -168,6 +169,15 @@ class LPIPSStyle(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
         self._synthetic_mark = self._fingerprint()
+
+    def train(self, mode=True):
+        """DELIBERATE DEVIATION: the perceptual net stays in eval mode whatever the parent module is switched to.
+        [UPSTREAM] builds it as `LPIPS().eval()` but defines no `train` override, so a Lightning fit's recursive `model.train()`
+        re-arms the `Dropout(0.5)` in front of every lin layer and the reference's training-time LPIPS value is that of a random
+        half of the feature channels, doubled -- an unbiased, noisy estimate of the eval-mode distance computed here (and by
+        every LPIPS evaluation outside training).  The metric is frozen (`requires_grad = False`), so nothing else depends on
+        the mode."""
+        return super().train(False)
 
     # ---- weights ---------------------------------------------------------------------------------------------------------------
     def _fingerprint(self):

@@ -139,6 +139,9 @@ class PoseLoss(LPIPSWithDiscriminator):
         # True: every pose-head term from one HIP kernel (ops.pose_losses); False keeps the per-term torch-op methods below (same
         # values; tests compare the two)
         self.fused_pose_terms = True
+        # True: with the discriminator off (disc_factor == 0) `g_loss` is still -mean D(x_rec) as the reference logs it (:285-292,331);
+        # False skips that forward pass and logs 0 (total loss and gradients do not depend on it)
+        self.log_exact_g_loss = True
         self.bbox_loss_fn = nn.MSELoss(reduction="none")
         self.fill_factor_loss_fn = nn.MSELoss(reduction="none")
         # `dataset_stats` (a dict) is an extension for runs without the pickle, which the reference does not ship
@@ -319,9 +322,13 @@ class PoseLoss(LPIPSWithDiscriminator):
             if self.disc_factor > 0.0:
                 logits_fake = self.discriminator(ops.mul_mask(reconstructions, mask_2d_bbox))
                 g_loss = -torch.mean(logits_fake * bg4)
+            elif self.log_exact_g_loss:
+                # discriminator off: the reference still evaluates D(x_rec) (its BatchNorm running statistics move too) and
+                # multiplies the term by an exact 0 (:285-292,305).  The forward runs here without a graph, so the logged
+                # `g_loss` and the discriminator's buffers are the reference's; the all-zero backward through D is skipped.
+                with torch.no_grad():
+                    g_loss = -torch.mean(self.discriminator(ops.mul_mask(reconstructions.detach(), mask_2d_bbox)) * bg4)
             else:
-                # discriminator off: its term is multiplied by an exact 0 in the reference, so it is not evaluated
-                # here (the logged g_loss is 0 instead of -mean D(x_rec); losses and gradients are identical)
                 g_loss = torch.zeros((), device=rgb_gt.device)
             if self.disc_factor > 0.0 and global_step > self.encoder_pretrain_steps:
                 try:

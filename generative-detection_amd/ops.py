@@ -963,9 +963,10 @@ def lpips_layer_distance(f0, f1, lin_w):
 _I31 = 0x7FFFFFF0
 
 
-def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32):
+def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32, cin_alg=None):
     """One odvae_conv_bf16 call.  mode 4 (1x1) flattens the pixels to [1][M/wi][wi]; images are processed in groups small enough
-    for the 2 GiB buffer descriptors."""
+    for the 2 GiB buffer descriptors.  cin_alg: the reduction width the algorithm has (3 for conv_in, whose image is zero-padded to
+    8 channels): the FLOP / byte figures handed to KERNEL_EVENTS are the direct-form work of SURVEY.md 8(d), not the padded work."""
     L = _L()
     n, cx, hi, wi = x.shape
     if mode in (0, 4):
@@ -980,8 +981,10 @@ def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32):
         tag = KERNEL_EVENTS.begin()
         _lib.check(L.odvae_conv_bf16(mode, x.data_ptr(), n, hi, wi, cx, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
                                      y.data_ptr(), ho, wo, int(out_f32), _lib.stream_ptr()), "conv_bf16(mode=%d)" % mode)
-        KERNEL_EVENTS.end("conv_bf16", 2.0 * 9 * cx * cout * n * ho * wo, tag,
-                          2.0 * n * hi * wi * cx + esz * n * ho * wo * cout * (2 if residual is not None else 1) + 2.0 * 9 * cx * cout)
+        ca = cin_alg or cx
+        px = hi * wi if mode == 3 else ho * wo     # mode 3 (data gradient of the stride-2 conv): nine taps per LOW-res pixel
+        KERNEL_EVENTS.end("conv_bf16", 2.0 * 9 * ca * cout * n * px, tag,
+                          2.0 * n * hi * wi * ca + esz * n * ho * wo * cout * (2 if residual is not None else 1) + 2.0 * 9 * ca * cout)
         return y
     per = hi * wi
     grp = max(1, min(n, _I31 // max(per * cx * 2, per * cout * esz)))
@@ -1015,7 +1018,7 @@ class _ConvB(Function):
             raise ValueError("conv_bf16: input has %d channels, weight expects %d" % (x.shape[1], cin))
         fwd_pack, dpack = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), "bf16")
         b = bias.detach().contiguous() if bias is not None else None
-        y = _conv_b_raw(mode, x, fwd_pack, cout, b, res, out_f32)
+        y = _conv_b_raw(mode, x, fwd_pack, cout, b, res, out_f32, cin_alg=cin)
         ctx.mode, ctx.has_bias, ctx.has_res, ctx.dpack = mode, bias is not None, residual is not None, dpack
         ctx.wshape = tuple(weight.shape)
         ctx.save_for_backward(x)
@@ -1055,22 +1058,35 @@ class _ConvB(Function):
             taps = ctx.wshape[2] * ctx.wshape[3]
             dwf = torch.empty((cp, cx) + tuple(ctx.wshape[2:]), dtype=torch.float32, device=x.device)
             dbf = torch.empty(cp, dtype=torch.float32, device=x.device) if fold_db else None
+            def _wgrad(xg, dyg, geo, ng, dw_out, db_out):
+                need = L.odvae_conv_wgrad_bf16_workspace_bytes(mode, geo[0], geo[4], geo[5], cx, cp)
+                wp, wn = _ws(need, x)
+                tag = KERNEL_EVENTS.begin(secondary=True)
+                _lib.check(L.odvae_conv_wgrad_bf16(mode, xg.data_ptr(), dyg.data_ptr(), *geo, dw_out.data_ptr(), _lib.ptr(db_out), wp, wn,
+                                                   _lib.stream_ptr()), "conv_wgrad_bf16(mode=%d)" % mode)
+                KERNEL_EVENTS.end("conv_wgrad_bf16", 2.0 * taps * cx * cp * ng * ho * wo, tag, 2.0 * ng * (hi * wi * cx + ho * wo * cp))
+
             if mode == 4:
+                # a 1x1 conv is one [pixels x cx]^T [pixels x cp] product; the kernel addresses with 32-bit offsets, so image groups
+                # of under 2 GiB are reduced one after the other (the same split the forward / data-gradient take in _conv_b_raw)
                 per = hi * wi
-                grp = max(1, min(n, _I31 // (per * max(cx, cp) * 2)))
-                if grp < n:
-                    raise NotImplementedError("1x1 weight gradient over more than 2 GiB of activations")
-                m = n * per
-                w16 = next(d for d in (16, 8, 4, 2, 1) if m % d == 0)
-                geo = (1, m // w16, w16, cx, m // w16, w16, cp)
+                grp = max(1, min(n, WGRAD_1X1_GROUP or _I31 // (per * max(cx, cp) * 2)))
+                for g0 in range(0, n, grp):
+                    ng = min(grp, n - g0)
+                    m = ng * per
+                    w16 = next(d for d in (16, 8, 4, 2, 1) if m % d == 0)
+                    geo = (1, m // w16, w16, cx, m // w16, w16, cp)
+                    if g0 == 0:
+                        _wgrad(x[g0:g0 + ng], dyb[g0:g0 + ng], geo, ng, dwf, dbf)
+                    else:
+                        dw_part = torch.empty_like(dwf)
+                        db_part = torch.empty_like(dbf) if fold_db else None
+                        _wgrad(x[g0:g0 + ng], dyb[g0:g0 + ng], geo, ng, dw_part, db_part)
+                        dwf += dw_part
+                        if fold_db:
+                            dbf += db_part
             else:
-                geo = (n, hi, wi, cx, ho, wo, cp)
-            need = L.odvae_conv_wgrad_bf16_workspace_bytes(mode, geo[0], geo[4], geo[5], cx, cp)
-            wp, wn = _ws(need, x)
-            tag = KERNEL_EVENTS.begin(secondary=True)
-            _lib.check(L.odvae_conv_wgrad_bf16(mode, x.data_ptr(), dyb.data_ptr(), *geo, dwf.data_ptr(), _lib.ptr(dbf), wp, wn,
-                                               _lib.stream_ptr()), "conv_wgrad_bf16(mode=%d)" % mode)
-            KERNEL_EVENTS.end("conv_wgrad_bf16", 2.0 * taps * cx * cp * n * ho * wo, tag, 2.0 * n * (hi * wi * cx + ho * wo * cp))
+                _wgrad(x, dyb, (n, hi, wi, cx, ho, wo, cp), n, dwf, dbf)
             dw = dwf if (cp == cout and cx == cin) else dwf[:cout, :cin].contiguous()
             if fold_db:
                 db = dbf if cp == cout else dbf[:cout].contiguous()
@@ -1084,6 +1100,9 @@ class _ConvB(Function):
                 _lib.check(L.odvae_colsum_bf16(dyb.data_ptr(), rows, cout, db.data_ptr(), wp, wn, _lib.stream_ptr()), "colsum_bf16")
         dres = dyb if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None
+
+
+WGRAD_1X1_GROUP = 0   # tests: force the image-group split of the 1x1 weight gradient at small sizes (0 = only past 2 GiB)
 
 
 def cast_pad_bf16(x, cp=None):

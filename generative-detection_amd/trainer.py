@@ -19,9 +19,12 @@ class _TrainerHandle:
 
 
 class Trainer:
-    def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=32.0, precision=None):
+    def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=32.0, precision=None,
+                 distributed=None):
         """optimizer_indices: which of the model's optimizers run each batch; (0,) is the "rec+KL only" benchmark
-        configuration (discriminator off, optimizer 1 skipped -- SURVEY.md 8(d))."""
+        configuration (discriminator off, optimizer 1 skipped -- SURVEY.md 8(d)).
+        distributed: None = data-parallel exactly when a process group is given or the default group has more than one rank
+        (what `strategy: ddp` amounts to, yaml:137); False = never (a single-process reference run inside a rank)."""
         self.model = model
         if precision is not None:   # lightning.trainer.precision of the yaml (:139): 32 or "bf16"
             model.set_precision(precision)
@@ -34,8 +37,10 @@ class Trainer:
                 o.materialize()
         model.trainer = _TrainerHandle(opts)
         self.reducers = None
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                         and torch.distributed.get_world_size() > 1):
+        if distributed is None:
+            distributed = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                        and torch.distributed.get_world_size() > 1)
+        if distributed:
             # the mean over ranks rides in the loss scale (training_batch), not in a pass over the gradient arena
             self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb, prescaled=True) for o in opts]
             self.reducers[0].broadcast_parameters(model)

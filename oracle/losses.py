@@ -196,6 +196,46 @@ class PoseLoss(nn.Module):
         d_weight = torch.clamp(d_weight, 0.0, 1e4).detach()
         return d_weight * self.discriminator_weight
 
+    def pose_terms(self, dec_pose, pose_gt, bbox_gt, fill_factor_gt, class_gt, class_gt_label, bbox_posterior, mask_bg=None):
+        """The pose-head terms of contperceptual.py:111-132 (compute_pose_loss), :176-181 (compute_class_loss), :183-189
+        (compute_bbox_loss), :191-205 (compute_pose_kl_loss), :207-212 (compute_fill_factor_loss), evaluated the way
+        forward() evaluates them (:259-271,278): masked sums over the batch divided by the number of samples whose class id is
+        not BACKGROUND_CLASS_IDX, 0 when there is none.  Returns the five unweighted terms and the four per-sample parts of
+        the pose term (t1 / t2 / t3 / v3, [B] each)."""
+        zero = torch.tensor(0.0)
+        if mask_bg is None:
+            mask_bg = torch.zeros_like(class_gt)
+            mask_bg[class_gt != BACKGROUND_CLASS_IDX] = 1
+        nbg = torch.sum(mask_bg)
+        pose_rec = dec_pose[:, :POSE_6D_DIM]
+        lhw_rec = dec_pose[:, POSE_6D_DIM:POSE_6D_DIM + LHW_DIM]
+        fill_factor_rec = dec_pose[:, POSE_6D_DIM + LHW_DIM:BBOX_DIM]
+        class_probs = dec_pose[:, BBOX_DIM:]
+        class_loss = sigmoid_focal_loss_mean(class_probs, class_gt)
+        bbox_loss = self.bbox_loss_fn(bbox_gt, lhw_rec) * mask_bg.unsqueeze(1)
+        bbox_loss = torch.sum(bbox_loss) / nbg if nbg > 0 else zero
+        # compute_pose_loss(pose_gt, pose_rec, mask_bg): (gt, pred) in the (pred, gt) slots (:269)
+        pred, gt = pose_gt, pose_rec
+        t1_loss, t2_loss, t3_loss = (self.pose_loss(pred[:, i], gt[:, i]) for i in range(3))
+        if self.train_on_yaw:
+            v3_loss = self.rot_loss_fn(torch.sin(pred[:, 3]), torch.sin(gt[:, 3]))
+        else:
+            v3_loss = self.pose_loss(pred[:, 3], gt[:, 3])
+        pose_loss = (t1_loss + t2_loss + t3_loss + v3_loss) * mask_bg
+        pose_loss = torch.sum(pose_loss) / nbg if nbg > 0 else zero
+        fill_factor_loss = self.fill_factor_loss_fn(fill_factor_gt, fill_factor_rec.squeeze()) * mask_bg
+        fill_factor_loss = torch.sum(fill_factor_loss) / nbg if nbg > 0 else zero
+        pose_kl = torch.zeros(len(class_gt_label), bbox_posterior.mean.size(1))
+        for idx, label in enumerate(class_gt_label):
+            if label == "background":
+                continue
+            cur = DiagonalGaussianDistribution(torch.cat((bbox_posterior.mean[idx].unsqueeze(1),
+                                                          bbox_posterior.logvar[idx].unsqueeze(1)), dim=1))
+            pose_kl[idx] = cur.kl(self.bbox_distribution_dict[label])
+        kl_loss_obj_bbox = torch.sum(pose_kl) / nbg if nbg > 0 else zero
+        return {"pose_loss": pose_loss, "class_loss": class_loss, "bbox_loss": bbox_loss, "fill_factor_loss": fill_factor_loss,
+                "kl_loss_bbox": kl_loss_obj_bbox, "t1": t1_loss, "t2": t2_loss, "t3": t3_loss, "v3": v3_loss}
+
     def forward(self, rgb_gt, mask_gt, pose_gt, dec_obj, dec_pose, class_gt, class_gt_label, bbox_gt, fill_factor_gt,
                 posterior_obj, bbox_posterior, optimizer_idx, global_step, mask_2d_bbox, last_layer=None, split="train"):
         assert mask_gt is None
@@ -211,29 +251,12 @@ class PoseLoss(nn.Module):
             reconstructions = reconstructions * mask_2d_bbox
             inputs_rgb = inputs_rgb * mask_2d_bbox
             reconstructions_rgb = reconstructions_rgb * mask_2d_bbox
-        pose_rec = dec_pose[:, :POSE_6D_DIM]
-        lhw_rec = dec_pose[:, POSE_6D_DIM:POSE_6D_DIM + LHW_DIM]
-        fill_factor_rec = dec_pose[:, POSE_6D_DIM + LHW_DIM:BBOX_DIM]
-        class_probs = dec_pose[:, BBOX_DIM:]
-
-        class_loss = sigmoid_focal_loss_mean(class_probs, class_gt)
+        t = self.pose_terms(dec_pose, pose_gt, bbox_gt, fill_factor_gt, class_gt, class_gt_label, bbox_posterior, mask_bg)
+        class_loss, bbox_loss, pose_loss, fill_factor_loss = t["class_loss"], t["bbox_loss"], t["pose_loss"], t["fill_factor_loss"]
         weighted_class_loss = self.class_weight * class_loss
-        bbox_loss = self.bbox_loss_fn(bbox_gt, lhw_rec) * mask_bg.unsqueeze(1)
-        bbox_loss = torch.sum(bbox_loss) / nbg if nbg > 0 else zero
         weighted_bbox_loss = self.bbox_weight * bbox_loss
-        # compute_pose_loss(pose_gt, pose_rec, mask_bg): (gt, pred) in the (pred, gt) slots (:269)
-        pred, gt = pose_gt, pose_rec
-        t1_loss, t2_loss, t3_loss = (self.pose_loss(pred[:, i], gt[:, i]) for i in range(3))
-        if self.train_on_yaw:
-            v3_loss = self.rot_loss_fn(torch.sin(pred[:, 3]), torch.sin(gt[:, 3]))
-        else:
-            v3_loss = self.pose_loss(pred[:, 3], gt[:, 3])
-        pose_loss = (t1_loss + t2_loss + t3_loss + v3_loss) * mask_bg
-        pose_loss = torch.sum(pose_loss) / nbg if nbg > 0 else zero
         weighted_pose_loss = self.pose_weight * pose_loss
         mask_loss, weighted_mask_loss = zero, zero  # use_mask_loss is forced off when no mask channel exists (:232,248)
-        fill_factor_loss = self.fill_factor_loss_fn(fill_factor_gt, fill_factor_rec.squeeze()) * mask_bg
-        fill_factor_loss = torch.sum(fill_factor_loss) / nbg if nbg > 0 else zero
         weighted_fill_factor_loss = self.fill_factor_weight * fill_factor_loss
 
         # _get_rec_loss :134-145
@@ -252,15 +275,7 @@ class PoseLoss(nn.Module):
         # _get_kl_loss :160-164
         kl_loss_obj = posterior_obj.kl() * mask_bg
         kl_loss_obj = torch.sum(kl_loss_obj) / nbg if nbg > 0 else zero
-        # compute_pose_kl_loss :191-205
-        pose_kl = torch.zeros(len(class_gt_label), bbox_posterior.mean.size(1))
-        for idx, label in enumerate(class_gt_label):
-            if label == "background":
-                continue
-            cur = DiagonalGaussianDistribution(torch.cat((bbox_posterior.mean[idx].unsqueeze(1),
-                                                          bbox_posterior.logvar[idx].unsqueeze(1)), dim=1))
-            pose_kl[idx] = cur.kl(self.bbox_distribution_dict[label])
-        kl_loss_obj_bbox = torch.sum(pose_kl) / nbg if nbg > 0 else zero
+        kl_loss_obj_bbox = t["kl_loss_bbox"]
 
         bg4 = mask_bg.unsqueeze(1).unsqueeze(1).unsqueeze(1)
         if optimizer_idx == 0:

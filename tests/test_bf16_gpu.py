@@ -77,6 +77,30 @@ def test_conv_bf16_fwd_bwd(hip_lib, mode, n, cin, cout, h, w):
     close(bd.grad, b.grad, F32_TOL, "db")
 
 
+def test_conv1x1_bf16_weight_gradient_over_image_groups(hip_lib):
+    """Past 2 GiB of activations the 1x1 weight gradient is reduced group of images by group of images (as forward and data
+    gradient are); forced here at a small size: the grouped result equals the one-launch result up to f32 summation order."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = cl_bf16(torch.randn(5, 64, 8, 8, generator=g))
+    wt = torch.randn(128, 64, 1, 1, generator=g).div(8).to(DEV)
+    b = (0.1 * torch.randn(128, generator=g)).to(DEV)
+    dy = cl_bf16(torch.randn(5, 128, 8, 8, generator=g))
+    grads = {}
+    for grp in (0, 2):
+        ops.WGRAD_1X1_GROUP = grp
+        try:
+            xd, wd, bd = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ops.conv1x1(xd, wd, bd, None).backward(dy)
+            grads[grp] = (wd.grad.clone(), bd.grad.clone())
+        finally:
+            ops.WGRAD_1X1_GROUP = 0
+    close(grads[2][0], grads[0][0], 1e-5, "dw grouped vs one launch")
+    close(grads[2][1], grads[0][1], 1e-5, "db grouped vs one launch")
+    wref = (dy.float().permute(1, 0, 2, 3).reshape(128, -1) @ x.float().permute(1, 0, 2, 3).reshape(64, -1).t()).reshape(128, 64, 1, 1)
+    close(grads[2][0], wref, F32_TOL, "dw grouped vs f32 product")
+
+
 def test_conv_bf16_f32_ends(hip_lib):
     """The f32 ends of the network: 3-channel image padded to 8 zero channels into conv_in; conv_out writing / differentiating a
     3-channel f32 reconstruction; encoder.conv_out writing f32 moments."""

@@ -37,8 +37,6 @@ def _compare(model, ref, batch, noise, grad_tol=5e-3, global_step=1):
         got = model.logged_metrics.get(key)
         if got is None or not torch.is_tensor(want) or want.numel() != 1:
             continue
-        if key.endswith(("g_loss", "d_weight")):   # disc_factor = 0: D is not evaluated here, g_loss is logged as 0
-            continue
         a, b = float(got), float(want)
         assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (key, a, b)
     if loss.requires_grad:

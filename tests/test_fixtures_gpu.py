@@ -105,8 +105,6 @@ def test_model_ch32_fixture(hip_lib):
     logged = model.logged_metrics
     for k in g.files:
         if k.startswith("log."):
-            if k.endswith("/g_loss"):   # discriminator off: the oracle still evaluates D(x_rec) and multiplies by an exact 0; the
-                continue                # product skips D and logs 0; losses and gradients are identical
             v = logged[k[4:]]
             close(torch.as_tensor(float(v)), g[k], 2e-3, k)
     rgb = model._rgb_input(batch)

@@ -38,6 +38,29 @@ def test_pose_encoder_matches_reference_module(impl):
     assert np.allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_full_pose_encoder_matches_reference_module(impl):
+    """The yaml's own instance (n = m = 16, hidden 500; yaml:46-54), forward and backward, as the REFERENCE's module
+    computed them (tests/golden/make_pose_encoder_golden.py: full); weights re-derived from the state_dict keys."""
+    from odvae_amd.synthetic import fill_state_procedural
+    g = np.load(os.path.join(GOLD, "pose_encoder_ref_full.npz"))
+    if impl == "oracle":
+        from oracle.autoencoder import PoseEncoderSpatialVAE
+    else:
+        from odvae_amd.pose_modules import PoseEncoderSpatialVAE
+    net = PoseEncoderSpatialVAE(num_classes=11, num_channels=16, n=16, m=16, activation="swish", hidden_dim=500, num_layers=2)
+    assert sum(p.numel() for p in net.parameters()) == 3089984
+    fill_state_procedural(net, seed=23)
+    z = torch.from_numpy(g["z"]).requires_grad_(True)
+    y = net(z)
+    y.backward(torch.from_numpy(g["gy"]))
+    assert np.allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(z.grad.numpy(), g["dz"], rtol=1e-5, atol=1e-7)
+    for k, p in net.named_parameters():
+        assert abs(p.grad.double().norm().item() - float(g["gnorm." + k])) <= 1e-5 * float(g["gnorm." + k]), k
+        assert np.allclose(p.grad.reshape(-1)[:64].numpy(), g["ghead." + k], rtol=1e-5, atol=1e-8), k
+
+
 def test_oracle_reproduces_config1_goldens():
     spec = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(GOLD, "make_oracle_goldens.py"))
     mod = importlib.util.module_from_spec(spec)
