@@ -18,7 +18,10 @@ FLAGS += os.environ.get("ODVAE_EXTRA_HIPCC_FLAGS", "").split()   # diagnostic bu
 # Per-file code-generation switches (none in use).  Tried on flash_attn_bf16.hip: `-mllvm -amdgpu-mfma-vgpr-form=1` removes the
 # 256 v_accvgpr_read/write per 32 MFMAs that hipcc's default register split puts at the loop back-edge of the attention kernels
 # (592 vs 565 TFLOP/s forward), but the D >= 256 forward kernels then return wrong results (tests/test_bf16_gpu.py), so it stays off.
-PER_FILE_FLAGS = {}
+# In use: -fno-slp-vectorize for the attention file.  At -O3 hipcc packs adjacent f32 multiplies / adds of the softmax sections into
+# v_pk_mul_f32 / v_pk_add_f32; beside MFMAs a packed f32 op costs more issue time than the two plain ones it replaces
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+PER_FILE_FLAGS = {"flash_attn_bf16.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):

@@ -478,10 +478,464 @@ __global__ __launch_bounds__(256) void flash_dkv_kernel(FlashP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward, second generation (D = 128 / 256): 512-thread blocks = 4 PAIRS of waves, <= 256 registers per wave.
+//
+// Why.  The kernels above keep a whole 32-row problem per wave: at D = 256 that is 330-430 registers, one wave per SIMD, hipcc
+// parks part of it in the accumulator file and moves it back for every use (360 v_accvgpr moves per 96 MFMAs in flash_dq, spills in
+// two instantiations), the dK/dV kernel only fits with the head dimension split over two blocks that BOTH recompute S and dP (9 matrix
+// products per tile pair instead of 7), and the +8-element row padding that makes the row reads conflict-free leaves the transposed
+// reads of the same tile 2.3-way conflicted (37-43 % of the LDS cycles, profiles/r02_flash_attn_pmc.txt).
+//
+// What.  Two waves share one 32-row problem and split it by ROLE, so that each half fits the 256 architectural registers (VGPR-form
+// MFMAs, no accumulator-file traffic) and two waves live on every SIMD -- one wave's softmax arithmetic runs under its partner's
+// MFMAs:
+//   dK/dV (key stationary, 32 keys per pair, 128 per block):
+//     wave A: S = Q K^T (K fragments in registers) -> P = exp2(c S - lse2) -> hands P to B through LDS -> dV^T += dO^T P   (all of D)
+//     wave B: dP = dO V^T (V fragments in registers) -> dS = P (dP - delta) scale                      -> dK^T += Q^T dS   (all of D)
+//     4 products per tile, none repeated; 32 MFMAs per wave and tile.
+//   dQ (query stationary, 32 queries per pair): producer / consumer, the consumer one tile behind
+//     wave A: S^T = K Q^T, dP^T = V dO^T (Q, dO fragments in registers) -> dS^T as packed bf16 fragments -> LDS
+//     wave B: dQ^T += K^T dS^T (all of D).   3 products per tile.
+//   One s_barrier per 32-row tile for everything: the pair hand-off (double-buffered), the landing of the tile two ahead, the release
+//   of the stage two behind.
+// Tiles arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, no staging registers, rows past T read as zeros) into a
+// ring of three stages, as unpadded rows of 2 D bytes whose 16-byte chunks are XOR-swizzled,
+//     chunk' = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)),
+// applied on the per-lane SOURCE address of the DMA (the LDS image of a DMA piece is lane-linear) and on every read: the
+// ds_read_b128 row reads (16 different rows per lane group -> 16 different chunk positions) and the ds_read_b64_tr_b16 transposed
+// reads (4 rows x 4 chunks per 32-lane half -> 16 different positions) of the SAME image are both conflict-free.
+// Blocks of one image share an XCD (one L2 streams its q / k / v / dO rows once).
+// ------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef ODVAE_FLASH_PAIR_PRIO
+#define ODVAE_FLASH_PAIR_PRIO 1
+#endif
+__device__ __forceinline__ bool flash_pair_prio() { return ODVAE_FLASH_PAIR_PRIO != 0; }
+// timing-only ablation builds (tools/ab_build.py ... -DODVAE_FLASH_ABL=mask; results are WRONG): 1 = no tile fetch inside the loop,
+// 2 = no barrier inside the loop, 4 = no softmax / dS arithmetic, 8 = no second product, 16 = no first product
+#ifndef ODVAE_FLASH_ABL
+#define ODVAE_FLASH_ABL 0
+#endif
+
+template <int D>
+struct PairGeom {
+  static constexpr int ROWB = 2 * D;              // bytes per tile row
+  static constexpr int CPR = D / 8;               // 16-byte chunks per row (16 or 32: the swizzle permutes the low four bits)
+  static constexpr int TILEB = 32 * ROWB;         // one 32-row tile
+  static constexpr int PIECES = TILEB / 1024;     // LDS-DMA wave-instructions per tile (8 or 16)
+  static constexpr int STAGEB = 2 * TILEB + 512;  // two tiles + two 256-byte row-constant slots
+  static constexpr int NSTAGE = 3;
+};
+
+__device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// LDS-DMA by inline asm: hipcc counts a `buffer_load ... lds` it knows about in vmcnt and, unable to tell the LDS-DMA's destination
+// from the tiles being read, waits for it (vmcnt(0)) in front of the next ds_read -- the fetch of the tile two periods ahead would be
+// waited for at the top of the period that issues it.  Hidden in an asm statement the load is invisible to that bookkeeping; the
+// kernels wait for it themselves (one `s_waitcnt vmcnt(0)` in front of each period's barrier).  M0 carries the LDS destination
+// (wave-uniform) and is restored; the s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t rsrc_words(const void* base, unsigned bytes) {
+  const uint64_t a = (uint64_t)base;
+  i32x4_t r;
+  r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
+#else
+  (void)rsrc; (void)lds_dst; (void)voff;
+#endif
+}
+__device__ __forceinline__ void lds_dma4(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
+#else
+  (void)rsrc; (void)lds_dst; (void)voff;
+#endif
+}
+// this wave's share of one tile: pieces wave, wave + 8 (, ...) of the [32][D] image of rows row0.. / columns col0.. of a [T][ld] matrix
+template <int D>
+__device__ __forceinline__ void dma_tile(i32x4_t rsrc, unsigned lds_tile, int row0, int T, int ld, int col0, int wave, int lane) {
+  using G = PairGeom<D>;
+#pragma unroll
+  for (int k = 0; k < G::PIECES / 8; ++k) {
+    const int j = wave + 8 * k;
+    const int slot = 64 * j + lane;                       // 16-byte slot of the LDS image this lane fills
+    const int row = slot / G::CPR, chp = slot % G::CPR;
+    const int ch = chp ^ swz16(row);                      // the chunk that belongs there
+    const unsigned voff = row0 + row < T ? (unsigned)(((row0 + row) * ld + col0 + 8 * ch) * 2) : 0x7FFFFFF0u;
+    lds_dma16(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_tile + 1024u * j)), voff);
+  }
+}
+// 32 per-row f32 constants (lse2 / delta of rows row0..) into a 256-byte slot: lanes 32..63 write zeros behind them
+__device__ __forceinline__ void dma_rowconst(i32x4_t rsrc, unsigned lds_slot, int row0, int T, int lane) {
+  const unsigned voff = (lane < 32 && row0 + lane < T) ? (unsigned)((row0 + lane) * 4) : 0x7FFFFFF0u;
+  lds_dma4(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_slot), voff);
+}
+
+// LDS addressing in 32-bit byte addresses.  Stage bases, row offsets (row * ROWB, ROWB = 256 or 512) and the 8192-byte step between
+// the two 16-row halves of a tile are multiples of ROWB, so the swizzled chunk field (bits 4.. of the address) can be set by an
+// add once and flipped by an XOR with a compile-time constant per read: one vector instruction per read, no table of addresses.
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_addr_of(const void* generic) { return (unsigned)(uintptr_t)(lds_char_t*)generic; }
+__device__ __forceinline__ u32x4 lds_ld128(unsigned a) { return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)a; }
+__device__ __forceinline__ f32x4 lds_ld128f(unsigned a) { return *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st128(unsigned a, u32x4 v) { *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = v; }
+__device__ __forceinline__ void lds_st128f(unsigned a, f32x4 v) { *(__attribute__((address_space(3))) f32x4*)(uintptr_t)a = v; }
+__device__ __forceinline__ s16x4 lds_ld_tr(unsigned a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a);
+#else
+  (void)a; return s16x4{0, 0, 0, 0};
+#endif
+}
+
+// Row reads (A operand of k-step ks: lane (li, h) takes chunk 2 ks + h of row li):  address = rowv ^ (32 ks),
+//   rowv = tile + li * ROWB + 16 * (swz16(li) ^ h)            (chunk (2 ks + h) ^ swz = (2 ks) ^ (swz ^ h))
+__device__ __forceinline__ unsigned row_lane_off(int li, int h, int rowb) { return (unsigned)(li * rowb + 16 * (swz16(li) ^ h)); }
+__device__ __forceinline__ bf16x8 row_frag(unsigned rowv, int ks) { return frag_from_u32x4(lds_ld128(rowv ^ (unsigned)(32 * ks))); }
+
+// Transposed reads (rows of the fragment = columns 32 dt .. of the tile, k = tile rows 16 s .. 16 s + 15 in accumulator order): lane
+// (g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3) reads 8 bytes of row r = 16 s + 4 (g >> 1) + q and of row r + 8, chunk
+// 4 dt + j, j = 2 (g & 1) + (pp >> 1).  With swz16(r) = (q << 2) | hk and swz16(r + 8) = (q << 2) | (hk + 2) (hk = g >> 1):
+//   address = (w ^ (64 dt)) + 8192 s,   w0 = tile + (4 hk + q) ROWB + 64 q + 16 (j ^ hk) + 8 (pp & 1),   w1 likewise for row + 8
+struct TrLane { unsigned w0, w1; };
+__device__ __forceinline__ TrLane tr_lane_off(int lane, int rowb) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, hk = g >> 1, j = 2 * (g & 1) + (pp >> 1);
+  TrLane t;
+  t.w0 = (unsigned)((4 * hk + q) * rowb + 64 * q + 16 * (j ^ hk) + 8 * (pp & 1));
+  t.w1 = (unsigned)((4 * hk + q + 8) * rowb + 64 * q + 16 * (j ^ (hk + 2)) + 8 * (pp & 1));
+  return t;
+}
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag_sw(unsigned tile, const TrLane& t, int s, int dt) {
+  constexpr unsigned HALF = 16 * PairGeom<D>::ROWB;
+  return frag_from_tr(lds_ld_tr(((tile + t.w0) ^ (unsigned)(64 * dt)) + HALF * s), lds_ld_tr(((tile + t.w1) ^ (unsigned)(64 * dt)) + HALF * s));
+}
+
+// blockIdx.x -> (image, 128-row block): the blocks of one image get ids that are equal mod 8, i.e. one XCD under round-robin placement
+__device__ __forceinline__ void pair_block_coords(int N, int QB, int& n, int& qb) {
+  const int id = blockIdx.x;
+  if ((N & 7) == 0) {
+    const int t = id >> 3;
+    qb = t % QB;
+    n = (t / QB) * 8 + (id & 7);
+  } else {
+    n = id / QB;
+    qb = id % QB;
+  }
+}
+
+// ---- dK / dV -------------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
+  using G = PairGeom<D>;
+  constexpr unsigned XB = 4096;                            // one pair's P tile, f32, [4 register quads][64 lanes][16 bytes]
+  extern __shared__ __attribute__((aligned(1024))) char smem_c[];
+  const unsigned smem = lds_addr_of(smem_c);
+  const unsigned xbuf = smem + G::NSTAGE * G::STAGEB;     // [2 buffers][4 pairs][XB]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, pair = wave & 3;             // role 0 = A (S, P, dV), 1 = B (dP, dS, dK)
+  // Waves w and w + 4 (a pair) share a SIMD.  A runs ahead: its MFMAs take the matrix pipe first, B's vector work (dS) hides under
+  // them at the start of a period and B's MFMAs fill the pipe while A computes the next tile's probabilities at its end.
+  if (role == 0 && flash_pair_prio()) __builtin_amdgcn_s_setprio(2);
+  const int QB = (p.T + 127) / 128;
+  int n, kb;
+  pair_block_coords(p.N, QB, n, kb);
+  const int key0 = kb * 128 + pair * 32;
+  const int C3 = 3 * p.C;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv + (int64_t)n * p.T * C3), 0, p.T * C3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.d_o + (int64_t)n * p.T * p.C), 0, p.T * p.C * 2, 0x00020000);
+  const i32x4_t wqkv = rsrc_words(p.qkv + (int64_t)n * p.T * C3, (unsigned)(p.T * C3 * 2));      // the same buffers, for the asm LDS-DMA
+  const i32x4_t wdo = rsrc_words(p.d_o + (int64_t)n * p.T * p.C, (unsigned)(p.T * p.C * 2));
+  const i32x4_t wl = rsrc_words(p.lse2 + (int64_t)n * p.T, (unsigned)(p.T * 4));
+  const i32x4_t wd = rsrc_words(p.delta + (int64_t)n * p.T, (unsigned)(p.T * 4));
+  const float c = p.scale * LOG2E;
+  const bool kok = key0 + li < p.T;
+  const int ntiles = (p.T + 31) / 32;
+
+  auto issue = [&](int t, unsigned stage) {   // tile t (query rows 32 t ..): Q rows, dO rows, lse2, delta
+    const unsigned st = smem + stage;
+    dma_tile<D>(wqkv, st, 32 * t, p.T, C3, 0, wave, lane);
+    dma_tile<D>(wdo, st + G::TILEB, 32 * t, p.T, p.C, 0, wave, lane);
+    if (wave == 0) dma_rowconst(wl, st + 2 * G::TILEB, 32 * t, p.T, lane);
+    if (wave == 1) dma_rowconst(wd, st + 2 * G::TILEB + 256, 32 * t, p.T, lane);
+  };
+  issue(0, 0);
+  if (ntiles > 1) issue(1, G::STAGEB);
+
+  // B fragments of this pair's 32 keys: K for role A, V for role B
+  bf16x8 bf[D / 16];
+  {
+    const int col = (role == 0 ? p.C : 2 * p.C);
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+      bf[ks] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rs, kok ? (unsigned)(((key0 + li) * C3 + col + 16 * ks + 8 * h) * 2) : 0x7FFFFFF0u, 0, 0));
+  }
+  f32x16 acc[D / 32];              // dV^T (A) or dK^T (B): [d][key]
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
+
+  // lane parts of the LDS addresses; the first product reads Q (A) / dO (B) by rows, the second dO (A) / Q (B) transposed
+  const unsigned rowl = smem + (role == 0 ? 0u : (unsigned)G::TILEB) + row_lane_off(li, h, G::ROWB);
+  TrLane trl = tr_lane_off(lane, G::ROWB);
+  trl.w0 += smem + (role == 0 ? (unsigned)G::TILEB : 0u);
+  trl.w1 += smem + (role == 0 ? (unsigned)G::TILEB : 0u);
+  const unsigned constl = smem + 2 * G::TILEB + 16 * h;    // + 256 for delta; row constants of register quad g at + 32 g
+  const unsigned xl = xbuf + pair * XB + lane * 16;
+
+  f32x16 s1;                       // A: S -> P;  B: dP, kept across the barrier
+  bf16x8 pf[2];                    // A: P fragments of the tile whose dV product comes next period;  B: dS fragments
+  // first product of the tile in `stage` alone (prologue only; inside the loop it is the second half of the MFMA stream below)
+  auto first_product_only = [&](unsigned stage) {
+    const unsigned rv = rowl + stage;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s1[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) s1 = mfma_bf16(row_frag(rv, ks), bf[ks], s1);
+  };
+  // A: P = exp2(c S - lse2) of the tile in `stage`, handed to B through exchange buffer `xsel`, and its fragments for the dV product
+  auto probabilities = [&](unsigned stage, unsigned xsel) {
+    if (ODVAE_FLASH_ABL & 4) { pf[0] = frag_from_acc(s1, 0); pf[1] = frag_from_acc(s1, 1); return; }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = lds_ld128f(constl + stage + 32 * g);
+      f32x4 pv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pv[e] = fast_exp2(fmaf(s1[4 * g + e], c, -l4[e])); s1[4 * g + e] = pv[e]; }
+      lds_st128f(xl + xsel + 1024 * g, pv);
+    }
+    pf[0] = frag_from_acc(s1, 0);
+    pf[1] = frag_from_acc(s1, 1);
+  };
+
+  unsigned cur = 0, nxt = G::STAGEB, fre = 2 * G::STAGEB;    // stages of tiles j, j + 1, j + 2 (= the one tile j - 1 leaves)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  first_product_only(0);
+  if (role == 0) probabilities(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // One period = one MFMA stream per wave: NB second-product MFMAs of tile j (column block dt = i / 2, k-step i & 1), then NA
+  // first-product MFMAs of tile j + 1.  Their LDS fragments travel in a ring RING MFMAs ahead, across the seam between the two products:
+  // a wave waits out an LDS latency once per period, not once per product.  In the last period the first product runs on a stale
+  // stage and its result is dropped.
+  constexpr int NB = D / 16, NA = D / 16, RING = D >= 256 ? 4 : 6;   // D = 256 sits at 256 registers with four fragments in flight
+  for (int j = 0; j < ntiles; ++j) {
+    if (j + 2 < ntiles && !(ODVAE_FLASH_ABL & 1)) issue(j + 2, fre);  // its last (transposed) reads ended before the barrier above
+    const unsigned xsel = (j & 1) * 4 * XB;
+    const unsigned rv = rowl + nxt;
+    bf16x8 ring[RING];
+    auto fetch = [&](int i) -> bf16x8 { return i < NB ? tr_frag_sw<D>(cur, trl, i & 1, i >> 1) : row_frag(rv, i - NB); };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = fetch(i);
+    if (role == 1 && !(ODVAE_FLASH_ABL & 4)) {   // dS = P (dP - delta) scale from A's probabilities (the ring's first reads are in flight)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 pv = lds_ld128f(xl + xsel + 1024 * g);
+        const f32x4 d4 = lds_ld128f(constl + cur + 256 + 32 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[4 * g + e] = pv[e] * fmaf(s1[4 * g + e], p.scale, -d4[e] * p.scale);
+      }
+      pf[0] = frag_from_acc(s1, 0);
+      pf[1] = frag_from_acc(s1, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < NB + NA; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (i < NB) {
+        if (!(ODVAE_FLASH_ABL & 8)) acc[i >> 1] = mfma_bf16(ring[i % RING], pf[i & 1], acc[i >> 1]);
+      } else {
+        if (i == NB) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+        }
+        if (!(ODVAE_FLASH_ABL & 16)) s1 = mfma_bf16(ring[i % RING], bf[i - NB], s1);
+      }
+      if (i + RING < NB + NA) ring[i % RING] = fetch(i + RING);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (role == 0) probabilities(nxt, xsel ^ (4 * XB));
+    const unsigned t = cur; cur = nxt; nxt = fre; fre = t;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(ODVAE_FLASH_ABL & 2)) __syncthreads();
+  }
+  if (kok) {
+    bf16_t* row = p.out + ((int64_t)n * p.T + key0 + li) * C3 + (role == 0 ? 2 * p.C : p.C);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 a;
+        a.x = pack_bf16x2(acc[dt][4 * g + 0], acc[dt][4 * g + 1]); a.y = pack_bf16x2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+        *reinterpret_cast<u32x2*>(row + dt * 32 + 8 * g + 4 * h) = a;
+      }
+  }
+}
+
+// ---- dQ ------------------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
+  using G = PairGeom<D>;
+  constexpr unsigned XB = 2048;                            // one pair's dS^T tile as two packed bf16 fragments: [2][64 lanes][16 bytes]
+  extern __shared__ __attribute__((aligned(1024))) char smem_c[];
+  const unsigned smem = lds_addr_of(smem_c);
+  const unsigned xbuf = smem + G::NSTAGE * G::STAGEB;     // [2 buffers][4 pairs][XB]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, pair = wave & 3;             // role 0 = A (S^T, dP^T, dS^T), 1 = B (dQ^T)
+  if (role == 0 && flash_pair_prio()) __builtin_amdgcn_s_setprio(2);   // the producer is the long pole: the consumer's MFMAs fill the gaps it leaves
+  const int QB = (p.T + 127) / 128;
+  int n, qb;
+  pair_block_coords(p.N, QB, n, qb);
+  const int q0 = qb * 128 + pair * 32;
+  const int C3 = 3 * p.C;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv + (int64_t)n * p.T * C3), 0, p.T * C3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.d_o + (int64_t)n * p.T * p.C), 0, p.T * p.C * 2, 0x00020000);
+  const float c = p.scale * LOG2E;
+  const bool qok = q0 + li < p.T;
+  const int ntiles = (p.T + 31) / 32;
+
+  const i32x4_t wqkv = rsrc_words(p.qkv + (int64_t)n * p.T * C3, (unsigned)(p.T * C3 * 2));      // the same buffer, for the asm LDS-DMA
+  auto issue = [&](int t, unsigned stage) {   // tile t (keys 32 t ..): K rows, V rows
+    const unsigned st = smem + stage;
+    dma_tile<D>(wqkv, st, 32 * t, p.T, C3, p.C, wave, lane);
+    dma_tile<D>(wqkv, st + G::TILEB, 32 * t, p.T, C3, 2 * p.C, wave, lane);
+  };
+  issue(0, 0);
+  if (ntiles > 1) issue(1, G::STAGEB);
+  const unsigned xl = xbuf + pair * XB + lane * 16;
+  // period t (0 .. ntiles): the producer multiplies tile t (stage cur), the consumer tile t - 1 (stage prv); tile t + 1 lands in nxt
+  unsigned prv = 2 * G::STAGEB, cur = 0, nxt = G::STAGEB;
+
+  if (role == 0) {
+    // ---- producer ----
+    bf16x8 qf[D / 16], dof[D / 16];
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      qf[ks] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rs, qok ? (unsigned)(((q0 + li) * C3 + 16 * ks + 8 * h) * 2) : 0x7FFFFFF0u, 0, 0));
+      dof[ks] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rdo, qok ? (unsigned)(((q0 + li) * p.C + 16 * ks + 8 * h) * 2) : 0x7FFFFFF0u, 0, 0));
+    }
+    const float lse = qok ? p.lse2[(int64_t)n * p.T + q0 + li] : 0.f;
+    const float dls = (qok ? p.delta[(int64_t)n * p.T + q0 + li] : 0.f) * p.scale;
+    const unsigned rowl = smem + row_lane_off(li, h, G::ROWB);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t <= ntiles; ++t) {
+      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      if (t < ntiles) {
+        const unsigned kr = rowl + cur;
+        f32x16 sa, da;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sa[i] = 0.f; da[i] = 0.f; }
+        {   // K / V row fragments RING MFMAs ahead (order pinned); the V tile sits TILEB behind the K tile: same XOR, immediate offset
+          constexpr int RING = 8, NM = 2 * (D / 16);
+          bf16x8 ring[RING];
+          auto fetch = [&](int i) -> bf16x8 { return frag_from_u32x4(lds_ld128((kr ^ (unsigned)(32 * (i >> 1))) + ((i & 1) ? (unsigned)G::TILEB : 0u))); };
+#pragma unroll
+          for (int i = 0; i < RING; ++i) ring[i] = fetch(i);
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i & 1) da = mfma_bf16(ring[i % RING], dof[i >> 1], da);      // dP^T[key][q]
+            else sa = mfma_bf16(ring[i % RING], qf[i >> 1], sa);             // S^T[key][q]
+            if (i + RING < NM) ring[i % RING] = fetch(i + RING);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        const bool tail = 32 * t + 32 > p.T;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float pr = fast_exp2(fmaf(sa[i], c, -lse));
+          if (tail && 32 * t + acc_row32(i, h) >= p.T) pr = 0.f;
+          sa[i] = pr * fmaf(da[i], p.scale, -dls);             // dS^T = P (dP - delta) scale
+        }
+        const unsigned xw = xl + (t & 1) * 4 * XB;
+        lds_st128(xw, __builtin_bit_cast(u32x4, frag_from_acc(sa, 0)));
+        lds_st128(xw + 1024, __builtin_bit_cast(u32x4, frag_from_acc(sa, 1)));
+      }
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // ---- consumer ----
+    f32x16 dq[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[dt][i] = 0.f;
+    TrLane trl = tr_lane_off(lane, G::ROWB);
+    trl.w0 += smem;
+    trl.w1 += smem;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t <= ntiles; ++t) {
+      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      if (t >= 1) {
+        const unsigned xr = xl + ((t - 1) & 1) * 4 * XB;
+        constexpr int RING = 8, NM = D / 16;      // dQ^T += K^T dS^T; transposed fragments RING MFMAs ahead
+        bf16x8 ring[RING];
+        auto fetch = [&](int i) -> bf16x8 { return tr_frag_sw<D>(prv, trl, i & 1, i >> 1); };
+#pragma unroll
+        for (int i = 0; i < RING; ++i) ring[i] = fetch(i);
+        bf16x8 db[2];
+        db[0] = frag_from_u32x4(lds_ld128(xr));
+        db[1] = frag_from_u32x4(lds_ld128(xr + 1024));
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_barrier(0);
+          dq[i >> 1] = mfma_bf16(ring[i % RING], db[i & 1], dq[i >> 1]);
+          if (i + RING < NM) ring[i % RING] = fetch(i + RING);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (qok) {
+      bf16_t* row = p.out + ((int64_t)n * p.T + q0 + li) * C3;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 v;
+          v.x = pack_bf16x2(dq[dt][4 * g + 0], dq[dt][4 * g + 1]);
+          v.y = pack_bf16x2(dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(row + dt * 32 + 8 * g + 4 * h) = v;
+        }
+    }
+  }
+}
+
+template <int D> constexpr int dkv_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 4096; }
+template <int D> constexpr int dq_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
+
 template <typename K>
-void launch_dyn(K kernel, dim3 grid, int lds_bytes, hipStream_t st, const FlashP& p) {
+void launch_dyn(K kernel, dim3 grid, int lds_bytes, hipStream_t st, const FlashP& p, int threads = 256) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, st, p);
+  hipLaunchKernelGGL(kernel, grid, dim3(threads), lds_bytes, st, p);
+}
+// ODVAE_FLASH_BWD_V1=1 keeps the first-generation backward kernels (one 32-row problem per wave) for in-process A/B runs
+bool flash_bwd_v1() {
+  static const bool v = [] { const char* e = getenv("ODVAE_FLASH_BWD_V1"); return e && e[0] == '1'; }();
+  return v;
 }
 constexpr int fwd_lds(int D, int DV, int KBT) { return 2 * (KBT * (D + 8) + KBT * (DV + 32)) * 2; }
 constexpr int dq_lds(int D, int KBT) { return 2 * (2 * KBT * (D + 8)) * 2; }
@@ -531,6 +985,17 @@ int odvae_flash_attn_bwd_bf16(const void* qkv, const void* o, const void* d_o, c
   hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.d_o, p.o, rows, C, delta_ws);
   ODVAE_LAUNCH_CHECK("flash_attn delta");
   const int qb = ceil_div(T, 128);
+  if (!flash_bwd_v1() && (C == 128 || C == 256) && (int64_t)qb * N < 0x7FFFFFFF) {
+    if (C == 256) {
+      launch_dyn(flash_dq_pair_kernel<256>, dim3(qb * N), dq_pair_lds<256>(), st, p, 512);
+      launch_dyn(flash_dkv_pair_kernel<256>, dim3(qb * N), dkv_pair_lds<256>(), st, p, 512);
+    } else {
+      launch_dyn(flash_dq_pair_kernel<128>, dim3(qb * N), dq_pair_lds<128>(), st, p, 512);
+      launch_dyn(flash_dkv_pair_kernel<128>, dim3(qb * N), dkv_pair_lds<128>(), st, p, 512);
+    }
+    ODVAE_LAUNCH_CHECK("flash_attn_bwd (pair kernels)");
+    return ODVAE_OK;
+  }
   switch (C) {
     case 64:
       launch_dyn(flash_dq_kernel<64, 64, 64>, dim3(qb, N, 1), dq_lds(64, 64), st, p);
