@@ -924,6 +924,167 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
   }
 }
 
+// ---- forward -----------------------------------------------------------------------------------------------------------------------
+// Same skeleton as the dQ kernel.  Producer A: S^T = K Q^T (Q fragments in registers), online softmax with the deferred maximum
+// (query on the lane: max / sum are in-register plus one lane^32 exchange), P^T as packed bf16 fragments + the row's rescale factor ->
+// LDS.  Consumer B, one tile behind: O^T += V^T P^T (all of D, V^T by transposed reads), rescaling O only in the rare periods in
+// which some row's reference maximum moved.
+template <int D>
+__global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
+  using G = PairGeom<D>;
+  constexpr unsigned XB = 2048 + 256;                      // one pair's P^T tile (two packed bf16 fragments) + 64 rescale factors
+  extern __shared__ __attribute__((aligned(1024))) char smem_c[];
+  const unsigned smem = lds_addr_of(smem_c);
+  const unsigned xbuf = smem + G::NSTAGE * G::STAGEB;     // [2 buffers][4 pairs][XB]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, pair = wave & 3;             // role 0 = A (S^T, softmax), 1 = B (O^T)
+  if (role == 0 && flash_pair_prio()) __builtin_amdgcn_s_setprio(2);
+  const int QB = (p.T + 127) / 128;
+  int n, qb;
+  pair_block_coords(p.N, QB, n, qb);
+  const int q0 = qb * 128 + pair * 32;
+  const int C3 = 3 * p.C;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.qkv + (int64_t)n * p.T * C3), 0, p.T * C3 * 2, 0x00020000);
+  const float c = p.scale * LOG2E;
+  const bool qok = q0 + li < p.T;
+  const int ntiles = (p.T + 31) / 32;
+  const i32x4_t wqkv = rsrc_words(p.qkv + (int64_t)n * p.T * C3, (unsigned)(p.T * C3 * 2));
+  auto issue = [&](int t, unsigned stage) {   // tile t (keys 32 t ..): K rows, V rows
+    const unsigned st = smem + stage;
+    dma_tile<D>(wqkv, st, 32 * t, p.T, C3, p.C, wave, lane);
+    dma_tile<D>(wqkv, st + G::TILEB, 32 * t, p.T, C3, 2 * p.C, wave, lane);
+  };
+  issue(0, 0);
+  if (ntiles > 1) issue(1, G::STAGEB);
+  const unsigned xl = xbuf + pair * XB + lane * 16;        // fragment slot of this lane
+  const unsigned al = xbuf + pair * XB + 2048 + lane * 4;  // rescale-factor slot of this lane
+  unsigned prv = 2 * G::STAGEB, cur = 0, nxt = G::STAGEB;
+
+  if (role == 0) {
+    // ---- producer ----
+    bf16x8 qf[D / 16];
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+      qf[ks] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rs, qok ? (unsigned)(((q0 + li) * C3 + 16 * ks + 8 * h) * 2) : 0x7FFFFFF0u, 0, 0));
+    const unsigned rowl = smem + row_lane_off(li, h, G::ROWB);
+    float m = NEG_BIG, l = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t <= ntiles; ++t) {
+      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      if (t < ntiles) {
+        const unsigned kr = rowl + cur;
+        f32x16 st;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+        {
+          constexpr int RING = 8, NM = D / 16;
+          bf16x8 ring[RING];
+#pragma unroll
+          for (int i = 0; i < RING; ++i) ring[i] = row_frag(kr, i);
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            st = mfma_bf16(ring[i % RING], qf[i], st);           // S^T[key][q]
+            if (i + RING < NM) ring[i % RING] = row_frag(kr, i + RING);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (32 * t + 32 > p.T) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (32 * t + acc_row32(i, h) >= p.T) st[i] = NEG_BIG;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])), fmaxf(fmaxf(st[4], st[5]), fmaxf(st[6], st[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[8], st[9]), fmaxf(st[10], st[11])), fmaxf(fmaxf(st[12], st[13]), fmaxf(st[14], st[15]))));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+        float alpha = 1.f;
+        if (__builtin_amdgcn_ballot_w64(mx > m + 8.f) != 0) {    // deferred maximum, as in flash_fwd_kernel
+          const float m_new = fmaxf(m, mx);
+          alpha = fast_exp2(m - m_new);
+          l *= alpha;
+          m = m_new;
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = fast_exp2(fmaf(st[i], c, -m)); ps += st[i]; }
+        l += ps;
+        const unsigned xs = (t & 1) * 4 * XB;
+        lds_st128(xl + xs, __builtin_bit_cast(u32x4, frag_from_acc(st, 0)));
+        lds_st128(xl + xs + 1024, __builtin_bit_cast(u32x4, frag_from_acc(st, 1)));
+        *(__attribute__((address_space(3))) float*)(uintptr_t)(al + xs) = alpha;
+      }
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    *(__attribute__((address_space(3))) float*)(uintptr_t)al = l;        // buffer 0 is free: its last reader finished before the barrier above
+    __syncthreads();
+    if (qok && h == 0) p.lse2[(int64_t)n * p.T + q0 + li] = m + log2f(l);
+  } else {
+    // ---- consumer ----
+    f32x16 ot[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ot[dt][i] = 0.f;
+    TrLane trl = tr_lane_off(lane, G::ROWB);
+    trl.w0 += smem + G::TILEB;          // the V tile of a stage
+    trl.w1 += smem + G::TILEB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t <= ntiles; ++t) {
+      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      if (t >= 1) {
+        const unsigned xs = ((t - 1) & 1) * 4 * XB;
+        constexpr int RING = 8, NM = D / 16;
+        bf16x8 ring[RING];
+        auto fetch = [&](int i) -> bf16x8 { return tr_frag_sw<D>(prv, trl, i & 1, i >> 1); };
+#pragma unroll
+        for (int i = 0; i < RING; ++i) ring[i] = fetch(i);
+        bf16x8 pb[2];
+        pb[0] = frag_from_u32x4(lds_ld128(xl + xs));
+        pb[1] = frag_from_u32x4(lds_ld128(xl + xs + 1024));
+        const float alpha = *(const __attribute__((address_space(3))) float*)(uintptr_t)(al + xs);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+          for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ot[dt][i] *= alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_barrier(0);
+          ot[i >> 1] = mfma_bf16(ring[i % RING], pb[i & 1], ot[i >> 1]);   // O^T[d][q] += V^T[d][key] P^T[key][q]
+          if (i + RING < NM) ring[i % RING] = fetch(i + RING);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    __syncthreads();
+    const float inv = 1.f / *(const __attribute__((address_space(3))) float*)(uintptr_t)al;
+    if (qok) {
+      bf16_t* orow = p.out + ((int64_t)n * p.T + q0 + li) * p.C;
+#pragma unroll
+      for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 v;
+          v.x = pack_bf16x2(ot[dt][4 * g + 0] * inv, ot[dt][4 * g + 1] * inv);
+          v.y = pack_bf16x2(ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2*>(orow + dt * 32 + 8 * g + 4 * h) = v;
+        }
+    }
+  }
+}
+
+template <int D> constexpr int fwd_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * (2048 + 256); }
 template <int D> constexpr int dkv_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 4096; }
 template <int D> constexpr int dq_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
 
@@ -932,7 +1093,7 @@ void launch_dyn(K kernel, dim3 grid, int lds_bytes, hipStream_t st, const FlashP
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
   hipLaunchKernelGGL(kernel, grid, dim3(threads), lds_bytes, st, p);
 }
-// ODVAE_FLASH_BWD_V1=1 keeps the first-generation backward kernels (one 32-row problem per wave) for in-process A/B runs
+// ODVAE_FLASH_BWD_V1=1 keeps the first-generation kernels (one 32-row problem per wave; forward and backward) for in-process A/B runs
 bool flash_bwd_v1() {
   static const bool v = [] { const char* e = getenv("ODVAE_FLASH_BWD_V1"); return e && e[0] == '1'; }();
   return v;
@@ -960,6 +1121,12 @@ int odvae_flash_attn_fwd_bf16(const void* qkv, int N, int T, int C, float scale,
   p.qkv = static_cast<const bf16_t*>(qkv); p.out = static_cast<bf16_t*>(o); p.lse2 = lse2; p.N = N; p.T = T; p.C = C; p.scale = scale;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int qb = ceil_div(T, 128);
+  if (!flash_bwd_v1() && (C == 128 || C == 256) && (int64_t)qb * N < 0x7FFFFFFF) {
+    if (C == 256) launch_dyn(flash_fwd_pair_kernel<256>, dim3(qb * N), fwd_pair_lds<256>(), st, p, 512);
+    else launch_dyn(flash_fwd_pair_kernel<128>, dim3(qb * N), fwd_pair_lds<128>(), st, p, 512);
+    ODVAE_LAUNCH_CHECK("flash_attn_fwd (pair kernel)");
+    return ODVAE_OK;
+  }
   switch (C) {
     case 64:  launch_dyn(flash_fwd_kernel<64, 64, 64>, dim3(qb, N, 1), fwd_lds(64, 64, 64), st, p); break;
     case 128: launch_dyn(flash_fwd_kernel<128, 128, 64>, dim3(qb, N, 1), fwd_lds(128, 128, 64), st, p); break;
