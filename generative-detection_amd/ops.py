@@ -461,9 +461,85 @@ class _Attention(Function):
         return dqkv
 
 
+# f32 path at long sequences.  _Attention keeps the probabilities P [N, T, T] for the backward: 64 MiB per image and block at T = 4 096
+# (256 x 256 input), but 1 GiB at T = 16 384 (512 x 512) -- five blocks at B = 32 would hold 160 GiB.  Past this budget (bytes of P per
+# block; ODVAE_ATTN_SCORE_BUDGET_GB) the block runs in groups of images through ONE score buffer and keeps only q, k, v and o: the
+# backward recomputes P group by group (a fifth product, as a fused attention would) -- no T x T tensor outlives its group.
+ATTN_SCORE_BUDGET = int(float(os.environ.get("ODVAE_ATTN_SCORE_BUDGET_GB", "4")) * 2 ** 30)
+
+
+class _AttentionRecompute(Function):
+    """softmax(q k^T * C^-0.5) v as _Attention, with the T x T scores living in a scratch buffer of at most ATTN_SCORE_BUDGET bytes."""
+
+    @staticmethod
+    def _views(t_, c):
+        off = t_.storage_offset()
+        return tuple(t_.as_strided((1,), (1,), off + i * c) for i in range(3))
+
+    @staticmethod
+    def _probabilities(L, qkv, g0, g, t, c, scale, p):
+        c3, sq = 3 * c, t * 3 * c
+        q, k, _ = _AttentionRecompute._views(qkv[g0:g0 + g], c)
+        gemm(0, 1, t, t, c, 1.0, q, c3, sq, k, c3, sq, p, t, t * t, batch=g)
+        _lib.check(L.odvae_softmax_rows_f32(p.data_ptr(), p.data_ptr(), g * t, t, scale, _lib.stream_ptr()), "softmax_rows")
+
+    @staticmethod
+    def forward(ctx, qkv, group):
+        L = _L()
+        qkv = _cl(qkv)
+        n, c3, h, w = qkv.shape
+        c, t = c3 // 3, h * w
+        scale = float(c) ** -0.5
+        o = _new_cl(n, c, h, w, qkv)
+        p = torch.empty(min(group, n), t, t, dtype=torch.float32, device=qkv.device)
+        for g0 in range(0, n, group):
+            g = min(group, n - g0)
+            _AttentionRecompute._probabilities(L, qkv, g0, g, t, c, scale, p)
+            v = _AttentionRecompute._views(qkv[g0:g0 + g], c)[2]
+            gemm(0, 0, t, c, t, 1.0, p, t, t * t, v, c3, t * c3, o[g0:g0 + g], c, t * c, batch=g)
+        ctx.group = group
+        ctx.save_for_backward(qkv, o)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        L = _L()
+        qkv, o = ctx.saved_tensors
+        do = _cl(do)
+        n, c3, h, w = qkv.shape
+        c, t = c3 // 3, h * w
+        scale = float(c) ** -0.5
+        sq = t * c3
+        group = max(1, ctx.group // 2)          # two score-sized buffers live here (P and dS)
+        dqkv = _new_cl(n, c3, h, w, qkv)
+        p = torch.empty(min(group, n), t, t, dtype=torch.float32, device=qkv.device)
+        dp = torch.empty_like(p)
+        drow = torch.empty(n * t, dtype=torch.float32, device=qkv.device)
+        _lib.check(L.odvae_rowdot_f32(do.data_ptr(), o.data_ptr(), n * t, c, drow.data_ptr(), _lib.stream_ptr()), "rowdot")
+        for g0 in range(0, n, group):
+            g = min(group, n - g0)
+            _AttentionRecompute._probabilities(L, qkv, g0, g, t, c, scale, p)
+            q, k, v = _AttentionRecompute._views(qkv[g0:g0 + g], c)
+            dq, dk, dv = _AttentionRecompute._views(dqkv[g0:g0 + g], c)
+            dog = do[g0:g0 + g]
+            gemm(1, 0, t, c, t, 1.0, p, t, t * t, dog, c, t * c, dv, c3, sq, batch=g)                       # dV = P^T dO
+            tag = KERNEL_EVENTS.begin(secondary=True)
+            _lib.check(L.odvae_gemm_softmax_bwd_f32(t, t, c, scale, dog.data_ptr(), c, t * c, v.data_ptr(), c3, sq, p.data_ptr(),
+                                                    drow.data_ptr() + 4 * g0 * t, t, dp.data_ptr(), t, t * t, g, _lib.stream_ptr()),
+                       "gemm_softmax_bwd")                                                                 # dS = scale P (dO V^T - D)
+            KERNEL_EVENTS.end("gemm_f32", 2.0 * t * t * c * g, tag, 4.0 * g * (2 * t * c + 2 * t * t))
+            gemm(0, 0, t, c, t, 1.0, dp, t, t * t, k, c3, sq, dq, c3, sq, batch=g)                          # dQ = dS K
+            gemm(1, 0, t, c, t, 1.0, dp, t, t * t, q, c3, sq, dk, c3, sq, batch=g)                          # dK = dS^T Q
+        return dqkv, None
+
+
 def attention_qkv(qkv):
     if qkv.dtype == BF16:
         return _FlashAttention.apply(qkv)
+    n, c3, h, w = qkv.shape
+    per_image = (h * w) ** 2 * 4
+    if n * per_image > ATTN_SCORE_BUDGET:
+        return _AttentionRecompute.apply(qkv, max(1, ATTN_SCORE_BUDGET // per_image))
     return _Attention.apply(qkv)
 
 

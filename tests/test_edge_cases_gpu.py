@@ -26,6 +26,7 @@ def _batch(classes, size=64, seed=11, holes=True):
 
 def _compare(model, ref, batch, noise, grad_tol=5e-3, global_step=1):
     model.train(); ref.train()
+    model.loss.log_exact_g_loss = True                   # log g_loss = -mean D(x_rec) as the reference does with the discriminator off
     model._global_step = ref.global_step = global_step   # > encoder_pretrain_steps (0): the rec / KL terms are in the total
     model.zero_grad(set_to_none=True)
     model.injected_noise = noise

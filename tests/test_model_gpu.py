@@ -61,6 +61,7 @@ def test_training_step_at_headline_shapes_matches_oracle(hip_lib):
 def check_step(model, ref, global_step, height, latent_hw):
     from odvae_amd import synthetic
     model.train(); ref.train()
+    model.loss.log_exact_g_loss = True
     model._global_step = ref.global_step = global_step
     batch = synthetic.make_batch(2, height, seed=5)
     noise = synthetic.make_noise(2, latent_hw, dropout_p=0.7, seed=6)

@@ -336,6 +336,36 @@ def test_attention(hip_lib, monkeypatch, n, c, h, w, fused):
     close(qd.grad, qr.grad, BWD_TOL, "attn dqkv")
 
 
+@pytest.mark.parametrize("n,c,h,w,budget_images", [(5, 64, 16, 16, 2), (3, 32, 10, 18, 1), (6, 256, 8, 16, 4)])
+def test_attention_with_score_budget(hip_lib, monkeypatch, n, c, h, w, budget_images):
+    """Past ops.ATTN_SCORE_BUDGET bytes of T x T scores the f32 AttnBlock runs group by group through one score buffer and recomputes
+    P in the backward (what lets the f32 path run 512 x 512 at B = 32: 16 384 tokens = 1 GiB of scores per image and block).
+    Forced here at small sizes, including a last group that is not full; same reference and tolerances as test_attention."""
+    from odvae_amd import ops
+    t = h * w
+    monkeypatch.setattr(ops, "ATTN_SCORE_BUDGET", budget_images * t * t * 4)
+    g = torch.Generator().manual_seed(c + h * w + n)
+    qkv = torch.randn(n, 3 * c, h, w, generator=g)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr[:, :c], qr[:, c:2 * c], qr[:, 2 * c:]
+    w_ = F.softmax(torch.bmm(q.reshape(n, c, t).permute(0, 2, 1), k.reshape(n, c, t)) * (c ** -0.5), dim=2)
+    o_ref = torch.bmm(v.reshape(n, c, t), w_.permute(0, 2, 1)).reshape(n, c, h, w)
+    go = torch.randn(o_ref.shape, generator=g)
+    o_ref.backward(go)
+    qd = qkv.to(dev()).requires_grad_(True)
+    o = ops.attention_qkv(qd)
+    assert o.grad_fn is not None and "Recompute" in type(o.grad_fn).__name__     # the budgeted path really ran
+    close(o, o_ref, FWD_TOL, "attn fwd (score budget)")
+    o.backward(go.to(dev()))
+    close(qd.grad, qr.grad, BWD_TOL, "attn dqkv (score budget)")
+    # same numbers as the all-resident path (same kernels, same order inside a group)
+    monkeypatch.setattr(ops, "ATTN_SCORE_BUDGET", 1 << 40)
+    q2 = qkv.to(dev()).requires_grad_(True)
+    o2 = ops.attention_qkv(q2)
+    o2.backward(go.to(dev()))
+    assert torch.equal(o2, o) and torch.equal(q2.grad, qd.grad)
+
+
 # ------------------------------------------------------------------------------------------------------
 def test_rescale_minmax(hip_lib):
     from odvae_amd import ops
