@@ -55,3 +55,49 @@ __device__ __forceinline__ bf16x8 frag_from_tr(s16x4 lo, s16x4 hi) {
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
+
+// ---- LDS in 32-bit byte addresses, LDS-DMA by inline asm (shared by the attention and the wide-tile conv kernels) ----------------
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ unsigned lds_addr_of(const void* generic) { return (unsigned)(uintptr_t)(lds_char_t*)generic; }
+__device__ __forceinline__ u32x4 lds_ld128(unsigned a) { return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)a; }
+__device__ __forceinline__ f32x4 lds_ld128f(unsigned a) { return *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st128(unsigned a, u32x4 v) { *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = v; }
+__device__ __forceinline__ void lds_st128f(unsigned a, f32x4 v) { *(__attribute__((address_space(3))) f32x4*)(uintptr_t)a = v; }
+__device__ __forceinline__ s16x4 lds_ld_tr(unsigned a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a);
+#else
+  (void)a; return s16x4{0, 0, 0, 0};
+#endif
+}
+
+// LDS-DMA by inline asm: hipcc counts a `buffer_load ... lds` it knows about in vmcnt and, unable to tell the LDS-DMA's destination
+// from the tiles being read, waits for it (vmcnt(0)) in front of the next ds_read -- the fetch of the tile two periods ahead would be
+// waited for at the top of the period that issues it.  Hidden in an asm statement the load is invisible to that bookkeeping; the
+// kernels wait for it themselves (one `s_waitcnt vmcnt(0)` in front of each period's barrier).  M0 carries the LDS destination
+// (wave-uniform) and is restored; the s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t rsrc_words(const void* base, unsigned bytes) {
+  const uint64_t a = (uint64_t)base;
+  i32x4_t r;
+  r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
+#else
+  (void)rsrc; (void)lds_dst; (void)voff;
+#endif
+}
+__device__ __forceinline__ void lds_dma4(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
+#else
+  (void)rsrc; (void)lds_dst; (void)voff;
+#endif
+}

@@ -243,6 +243,189 @@ __global__ __launch_bounds__(256, MINW) void conv_bf16_kernel(ConvB p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Wide tile for the stride-1 3x3 convs with more than 64 output channels (every ResnetBlock conv and its data gradient):
+// block = 16 x 16 output pixels x 128 output channels, 4 waves of 64 co x 128 px (2 x 4 MFMA tiles).
+//
+// Why.  In conv_bf16_kernel's 128-pixel tile every MFMA needs 512 B of weights through the vector L1 (64 B/clk per CU): as many
+// cycles as the MFMAs themselves.  Here one 16-byte weight load feeds four MFMAs (256 B per MFMA).  The first attempt at this tile
+// (64-channel chunks, halo staged through registers: 424 registers, 93 KB of LDS, ONE 4-wave block per CU) ran at 0.56x the narrow
+// tile.  This form fits two blocks per CU: __launch_bounds__(256, 2) keeps it inside the 256 architectural registers (VGPR-form
+// MFMAs, no accumulator-file copies), the halo takes no registers at all -- it arrives by LDS-DMA (asm, bf16_common.h) into a ring of
+// three 21 KB stages, 32 channels per chunk, two chunks ahead, ONE barrier per chunk -- and the LDS image is unpadded [halo px][32 ch]
+// with the 16-byte chunk index XOR-swizzled by (px >> 2) & 3, so that sixteen consecutive pixels read by one ds_read_b128 lane group
+// fall on sixteen different chunk positions (the swizzle is applied to the DMA's per-lane source address and to every read).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_bf16_wide_kernel(ConvB p) {
+  constexpr int KC = 32, KS = 2, TAPS = 9, NIT = TAPS * KS, TH = 16;
+  constexpr int HW = TW + 2, HPIX = (TH + 2) * HW;              // 18 x 18 halo pixels
+  constexpr int PIECES = (HPIX * 4 + 63) / 64;                  // 21 LDS-DMA wave-instructions (1 KiB) per stage
+  constexpr unsigned STAGEB = PIECES * 1024, NSTG = 3;
+  constexpr int WCT = 2, WPT = 4;
+  extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
+  const unsigned lds0 = lds_addr_of(smem);
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 1, wpx = wave & 1;
+
+  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int co0 = blockIdx.y * 128;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int esz = p.out_f32 ? 4 : 2;
+  const unsigned OOB = 0x7FFFFFF0u;
+
+  // ---- halo fetch plan: piece j = wave + 4 k; lane fills 16-byte slot 64 j + lane = (halo pixel hp, chunk position chp) ----------
+  const i32x4_t xw = rsrc_words(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin, (unsigned)(p.Hi * p.Wi * p.Cin * 2));
+  constexpr int NPW = (PIECES + 3) / 4;                           // pieces per wave (6; the last round only has piece 20)
+  unsigned hvoff[NPW];
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    const int slot = 64 * (wave + 4 * k) + lane;
+    const int hp = slot >> 2, chp = slot & 3;
+    const int ch = chp ^ ((hp >> 2) & 3);
+    const int iy = iy0 + hp / HW, ix = ix0 + hp % HW;
+    const bool ok = hp < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    hvoff[k] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * ch) * 2) : OOB;
+  }
+  auto issue = [&](int chunk, unsigned stage) {
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int j = wave + 4 * k;
+      if (j < PIECES)      // wave-uniform
+        lds_dma16(xw, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage + 1024u * j)), hvoff[k] + (unsigned)(chunk * KC * 2));
+    }
+  };
+  const int nchunks = p.CinP / KC;
+  issue(0, 0);
+  if (nchunks > 1) issue(1, STAGEB);
+
+  // this lane's pixel in each of its four pixel tiles (column of the MFMA result)
+  unsigned pixoff[WPT];
+  int hp0[WPT];
+#pragma unroll
+  for (int pt = 0; pt < WPT; ++pt) {
+    const int pm = (wpx * WPT + pt) * 32 + li;
+    const int pr = pm / TW, pc = pm % TW;
+    const int oy = oy0 + pr, ox = ox0 + pc;
+    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
+    hp0[pt] = pr * HW + pc;
+  }
+
+  // accumulators start at bias + residual: the epilogue is stores only
+  f32x16 acc[WCT][WPT];
+  {
+    const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) {
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.residual) {
+            const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
+            rv[0] = bf16_lo(v.x); rv[1] = bf16_hi(v.x); rv[2] = bf16_lo(v.y); rv[3] = bf16_hi(v.y);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ct][pt][4 * g + j] = bv[j] + rv[j];
+        }
+      }
+  }
+
+  // ---- operand fetch -------------------------------------------------------------------------------------------------------
+  const int KT = p.CinP / 16, CT = p.CoutP / 32;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.wpk), 0, TAPS * KT * CT * 1024, 0x00020000);
+  const int ct0 = co0 / 32 + wco * WCT;
+  const unsigned lane16 = lane * 16;
+  auto load_a = [&](int ch, int it, bf16x8 (&a)[WCT]) {   // step `it` of chunk `ch`; it >= NIT runs into chunk ch + 1 (or past the pack: zeros)
+    const int c2 = ch + it / NIT, i2 = it % NIT;
+    const int tap = i2 / KS, ks = i2 % KS;
+    const unsigned base = (unsigned)(((tap * KT + c2 * KS + ks) * CT + ct0) * 1024) + lane16;
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, base + ct * 1024, 0, 0));
+  };
+  // pixel fragment of step (tap, ks): lane (pixel, h) reads chunk 2 ks + h of halo pixel hp = hp0 + kh * 18 + kw, stored at chunk
+  // position (2 ks + h) ^ ((hp >> 2) & 3)
+  auto load_b = [&](unsigned stage_addr, int it, bf16x8 (&b)[WPT]) {
+    const int tap = it / KS, ks = it % KS;
+    const int toff = (tap / 3) * HW + (tap % 3);
+#pragma unroll
+    for (int pt = 0; pt < WPT; ++pt) {
+      const unsigned hp = (unsigned)(hp0[pt] + toff);
+      const unsigned pos = ((hp >> 2) ^ (unsigned)(2 * ks + h)) & 3u;
+      b[pt] = frag_from_u32x4(lds_ld128(stage_addr + hp * 64u + pos * 16u));
+    }
+  };
+
+  constexpr int RA = 3, PA = RA - 1;
+  static_assert(NIT % RA == 0, "weight ring");
+  bf16x8 abuf[RA][WCT], bbuf[2][WPT];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) load_a(0, j, abuf[j]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  unsigned cur = 0, nxt = STAGEB, fre = 2 * STAGEB;
+  for (int ch = 0; ch < nchunks; ++ch) {
+#ifndef ODVAE_CONVW_ABL_NODMA
+    if (ch + 2 < nchunks) issue(ch + 2, fre);          // the stage chunk ch - 1 left: its last reads ended before the barrier above
+#endif
+    const unsigned sa = lds0 + cur;
+    load_b(sa, 0, bbuf[0]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      load_a(ch, it + PA, abuf[(it + PA) % RA]);
+      if (it + 1 < NIT) load_b(sa, it + 1, bbuf[(it + 1) % 2]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(abuf[it % RA][ct], bbuf[it % 2][pt], acc[ct][pt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    { const unsigned o = cur; cur = nxt; nxt = fre; fre = o; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: stores only ------------------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      static_cast<char*>(p.y) + (int64_t)n * p.Ho * p.Wo * p.Cout * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
+#pragma unroll
+  for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int pt = 0; pt < WPT; ++pt) {
+        if (p.out_f32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ct][pt][4 * g + j]), yrsrc, off, 0, 0);
+          }
+        } else {
+          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+          u32x2 v;
+          v.x = pack_bf16x2(acc[ct][pt][4 * g + 0], acc[ct][pt][4 * g + 1]);
+          v.y = pack_bf16x2(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
+        }
+      }
+    }
+}
+
 // OIHW f32 (kh x kw = 3x3 or 1x1) -> bf16 fragment packs.
 //   fwd:   reduce over Cin, rows = Cout:   W[tap][co][ci]
 //   dgrad: reduce over Cout, rows = Cin:   W'[tap][ci][co] = w[co][ci][flip(tap)]   (MODE 0 / 4 data gradient; MODE 3 uses
@@ -303,7 +486,13 @@ void launch_by_cout(ConvB& p, hipStream_t st) {
 
 }  // namespace
 
+static int g_wide_tile = -1;   // -1: not chosen yet (environment decides at the first call)
+
 extern "C" {
+
+// 1: stride-1 3x3 convs with Cout > 64, Cin % 32 == 0, Ho >= 16 run on the wide tile (conv_bf16_wide_kernel); 0: on the 128-pixel tile
+// (default; ODVAE_CONV_BF16_WIDE2 presets it).  Returns the previous setting (-1 = environment not read yet).
+int odvae_conv_bf16_select_wide_tile(int on) { const int prev = g_wide_tile; g_wide_tile = on ? 1 : 0; return prev; }
 
 // reduction-channel padding (16 per MFMA k-step; the kernel walks chunks of 32 or 64) and output-channel padding of a pack
 int odvae_conv_bf16_reduce_pad(int c) { return c % 64 == 0 ? c : pad_to(c, 32); }
@@ -357,6 +546,28 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool k64 = p.CinP % 64 == 0;
+  // ODVAE_CONV_BF16_WIDE2=1: stride-1 3x3 convs with more than 64 output channels and whole 32-channel chunks on the wide tile
+  // (conv_bf16_wide_kernel).  Off by default: measured on the layers it is 3-7 % faster than the 128-pixel tile (795 vs 744 TFLOP/s at
+  // 128 -> 128 @256x256, 951 vs 920 at 256 -> 256 @128x128, B=32), over a whole bf16 step the two are equal (405.6 vs 406.2 images/s at
+  // 256x256, 70.6 vs 70.8 at 512x512).  What it showed (timing-only build without the in-loop halo DMA: +15 / +22 %): a wave's vector
+  // memory operations complete in issue order, so every weight load issued behind the halo fetch of the chunk two ahead waits for that
+  // fetch's HBM latency -- two steps of weight prefetch do not cover it.  The same holds for the register-staged halo loads of
+  // conv_bf16_kernel.  The structural fix is weights through LDS as well (no per-step global loads); DESIGN.md 9.
+  if (g_wide_tile < 0) g_wide_tile = getenv("ODVAE_CONV_BF16_WIDE2") ? atoi(getenv("ODVAE_CONV_BF16_WIDE2")) : 0;
+  const int wide2 = g_wide_tile;
+  if (mode == 0 && wide2 && Cout > 64 && Cin % 32 == 0 && Ho >= 16) {
+    p.tiles_y = ceil_div(Ho, 16);
+    constexpr int lds_bytes = 3 * 21 * 1024;
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      once = true;
+    }
+    ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
+    hipLaunchKernelGGL(conv_bf16_wide_kernel, dim3(N * p.tiles_x * p.tiles_y, ceil_div(Cout, 128)), dim3(256), lds_bytes, st, p);
+    ODVAE_LAUNCH_CHECK("conv_bf16 (wide tile)");
+    return ODVAE_OK;
+  }
   switch (mode) {
     // (32-channel chunks at three blocks per CU -- __launch_bounds__(256, 3): 168 registers, 29 KB of LDS -- measured the same as
     // 64-channel chunks at two blocks per CU: 747 vs 740 TFLOP/s at 128 channels, B=32)

@@ -531,36 +531,6 @@ struct PairGeom {
 
 __device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-// LDS-DMA by inline asm: hipcc counts a `buffer_load ... lds` it knows about in vmcnt and, unable to tell the LDS-DMA's destination
-// from the tiles being read, waits for it (vmcnt(0)) in front of the next ds_read -- the fetch of the tile two periods ahead would be
-// waited for at the top of the period that issues it.  Hidden in an asm statement the load is invisible to that bookkeeping; the
-// kernels wait for it themselves (one `s_waitcnt vmcnt(0)` in front of each period's barrier).  M0 carries the LDS destination
-// (wave-uniform) and is restored; the s_nop covers the SALU-write-M0 -> LDS-DMA hazard.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4_t rsrc_words(const void* base, unsigned bytes) {
-  const uint64_t a = (uint64_t)base;
-  i32x4_t r;
-  r.x = (int)(unsigned)a; r.y = (int)((unsigned)(a >> 32) & 0xFFFFu); r.z = (int)bytes; r.w = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
-#else
-  (void)rsrc; (void)lds_dst; (void)voff;
-#endif
-}
-__device__ __forceinline__ void lds_dma4(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc) : "memory");
-#else
-  (void)rsrc; (void)lds_dst; (void)voff;
-#endif
-}
 // this wave's share of one tile: pieces wave, wave + 8 (, ...) of the [32][D] image of rows row0.. / columns col0.. of a [T][ld] matrix
 template <int D>
 __device__ __forceinline__ void dma_tile(i32x4_t rsrc, unsigned lds_tile, int row0, int T, int ld, int col0, int wave, int lane) {
@@ -579,23 +549,6 @@ __device__ __forceinline__ void dma_tile(i32x4_t rsrc, unsigned lds_tile, int ro
 __device__ __forceinline__ void dma_rowconst(i32x4_t rsrc, unsigned lds_slot, int row0, int T, int lane) {
   const unsigned voff = (lane < 32 && row0 + lane < T) ? (unsigned)((row0 + lane) * 4) : 0x7FFFFFF0u;
   lds_dma4(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_slot), voff);
-}
-
-// LDS addressing in 32-bit byte addresses.  Stage bases, row offsets (row * ROWB, ROWB = 256 or 512) and the 8192-byte step between
-// the two 16-row halves of a tile are multiples of ROWB, so the swizzled chunk field (bits 4.. of the address) can be set by an
-// add once and flipped by an XOR with a compile-time constant per read: one vector instruction per read, no table of addresses.
-typedef __attribute__((address_space(3))) char lds_char_t;
-__device__ __forceinline__ unsigned lds_addr_of(const void* generic) { return (unsigned)(uintptr_t)(lds_char_t*)generic; }
-__device__ __forceinline__ u32x4 lds_ld128(unsigned a) { return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)a; }
-__device__ __forceinline__ f32x4 lds_ld128f(unsigned a) { return *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)a; }
-__device__ __forceinline__ void lds_st128(unsigned a, u32x4 v) { *(__attribute__((address_space(3))) u32x4*)(uintptr_t)a = v; }
-__device__ __forceinline__ void lds_st128f(unsigned a, f32x4 v) { *(__attribute__((address_space(3))) f32x4*)(uintptr_t)a = v; }
-__device__ __forceinline__ s16x4 lds_ld_tr(unsigned a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)a);
-#else
-  (void)a; return s16x4{0, 0, 0, 0};
-#endif
 }
 
 // Row reads (A operand of k-step ks: lane (li, h) takes chunk 2 ks + h of row li):  address = rowv ^ (32 ks),

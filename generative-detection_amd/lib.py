@@ -77,6 +77,7 @@ PROTOTYPES = {
     "odvae_linear_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "odvae_linear_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     # bf16 mixed-precision path
+    "odvae_conv_bf16_select_wide_tile": (_I, [_I]),
     "odvae_conv_bf16_reduce_pad": (_I, [_I]),
     "odvae_conv_bf16_out_pad": (_I, [_I]),
     "odvae_conv_bf16_pack_elems": (_Z, [_I, _I, _I]),

@@ -22,6 +22,8 @@ except Exception:  # noqa: BLE001
             self._logged = {}
             self.trainer = None
             self._toggled = None
+            self.logger = None          # anything with a `save_dir` (callbacks.ImageLogger); trainer.Trainer(logger=...) sets it
+            self.current_epoch = 0
 
         # ---- what PL provides and the model reads -----------------------------------------------------
         @property

@@ -16,10 +16,18 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False):
+    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False, comm_dtype=None):
         """prescaled=True: the caller back-propagates `loss * inv_world` (trainer.Trainer does), so the summed buckets
-        already ARE the mean and finish() needs no averaging pass over the arena (284 MB for optimizer 0)."""
+        already ARE the mean and finish() needs no averaging pass over the arena (284 MB for optimizer 0).
+        comm_dtype=torch.bfloat16: a bucket travels as bf16 -- cast into a staging buffer when its last gradient lands, all-reduced
+        there, written back to the f32 arena in finish() -- half the bytes per xGMI link (142 MB instead of 284 MB per generator
+        step).  For the bf16 step, whose backward is a third as long as the f32 one: with the default f32 buckets the
+        exchange is 3-4 % of that step unless fully hidden.  The mean of world <= 8 bf16-rounded, pre-scaled gradients carries a
+        relative error of about 2^-9 per element, the size of the rounding the bf16 activations already put into them; master
+        weights, Adam moments and the clip norm stay f32."""
         self.group = process_group
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self._staging = {}
         self.world = dist.get_world_size(process_group)
         self.inv_world = 1.0 / self.world
         self.prescaled = bool(prescaled)
@@ -97,7 +105,14 @@ class GradReducer:
             self.optimizer.gather_grads(self.bucket_members[b])
         self._launched.add(b)
         self.launch_order.append(b)
-        self._works.append(dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.comm_dtype is None:
+            self._works.append(dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            buf = self._staging.get(b)
+            if buf is None:
+                buf = self._staging[b] = torch.empty(e - s, dtype=self.comm_dtype, device=self.arena.device)
+            buf.copy_(self.arena[s:e])                  # f32 -> bf16, one pass over the bucket
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Issue the collectives of buckets that only some of their parameters reached (same set on every rank,
@@ -107,6 +122,10 @@ class GradReducer:
             self._launch(b)
         for w in self._works:
             w.wait()
+        if self.comm_dtype is not None:
+            for b in self.launch_order:
+                s, e = self.buckets[b]
+                self.arena[s:e].copy_(self._staging[b])   # bf16 -> f32 back into the arena
         if not self.prescaled:
             for b in self.launch_order:
                 s, e = self.buckets[b]

@@ -34,6 +34,7 @@ def parse(argv):
     ap.add_argument("--steps", type=int, default=2, help="batches to run")
     ap.add_argument("--height", type=int, default=256, help="synthetic crop size (the yaml's patch_height)")
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("-l", "--logdir", default=None, help="if given, the yaml's lightning.callbacks run and ImageLogger writes below it")
     return ap.parse_known_args(argv)
 
 
@@ -55,7 +56,15 @@ def main(argv=None):
     model = instantiate_from_config(config.model)
     configure_learning_rate(config, model, trainer_cfg, scale_lr=opt.scale_lr, ngpu=1)
     model = model.to(opt.device).train()
-    trainer = Trainer(model, gradient_clip_val=trainer_cfg.get("gradient_clip_val", None), precision=trainer_cfg.get("precision", None))
+    callbacks, logger = [], None
+    if opt.logdir:   # the callbacks section of the yaml (train.py:452-463 instantiates them the same way)
+        class _Logger:
+            save_dir = opt.logdir
+        logger = _Logger()
+        for name, cb_cfg in lightning.get("callbacks", Config.create()).items():
+            callbacks.append(instantiate_from_config(cb_cfg))
+    trainer = Trainer(model, gradient_clip_val=trainer_cfg.get("gradient_clip_val", None), precision=trainer_cfg.get("precision", None),
+                      callbacks=callbacks, logger=logger)
     bs = config.data.params.batch_size
     for step in range(opt.steps):
         batch = synthetic.make_batch(bs, opt.height, seed=opt.seed + step)

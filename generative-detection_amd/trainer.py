@@ -20,12 +20,20 @@ class _TrainerHandle:
 
 class Trainer:
     def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=32.0, precision=None,
-                 distributed=None):
+                 distributed=None, comm_dtype=None, callbacks=(), logger=None):
         """optimizer_indices: which of the model's optimizers run each batch; (0,) is the "rec+KL only" benchmark
         configuration (discriminator off, optimizer 1 skipped -- SURVEY.md 8(d)).
+        comm_dtype: dtype of the gradient buckets on the wire; None = f32, except under precision "bf16" with bucket_mb left at its
+        default, where the buckets travel as bf16 in 16 MB pieces (parallel.GradReducer).
         distributed: None = data-parallel exactly when a process group is given or the default group has more than one rank
         (what `strategy: ddp` amounts to, yaml:137); False = never (a single-process reference run inside a rank)."""
         self.model = model
+        # callbacks: objects with the pytorch_lightning.Callback hooks used by the reference's yaml (callbacks.ImageLogger, ...);
+        # `on_train_batch_end` runs after the last optimizer step of a batch, as under PL's automatic optimisation.  logger: anything
+        # with a `save_dir` (ImageLogger writes <save_dir>/images/<split>/...); it becomes `model.logger`.
+        self.callbacks = list(callbacks)
+        if logger is not None:
+            model.logger = logger
         if precision is not None:   # lightning.trainer.precision of the yaml (:139): 32 or "bf16"
             model.set_precision(precision)
         self.clip = gradient_clip_val
@@ -42,7 +50,12 @@ class Trainer:
                                                         and torch.distributed.get_world_size() > 1)
         if distributed:
             # the mean over ranks rides in the loss scale (training_batch), not in a pass over the gradient arena
-            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb, prescaled=True) for o in opts]
+            if comm_dtype is None and precision is not None and str(precision).lower().startswith("bf16"):
+                comm_dtype = torch.bfloat16
+                if bucket_mb == 32.0:
+                    bucket_mb = 16.0     # f32 megabytes of arena per bucket = 8 MB on the wire: ~18 collectives inside a ~50 ms backward
+            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb, prescaled=True, comm_dtype=comm_dtype)
+                             for o in opts]
             self.reducers[0].broadcast_parameters(model)
 
     # PL-1.9 toggle_optimizer: parameters owned by the *other* optimizers stop requiring grad; parameters in no
@@ -92,6 +105,8 @@ class Trainer:
                 self._untoggle(saved)
             model._global_step += 1
             losses.append(loss.detach())
+        for cb in self.callbacks:
+            cb.on_train_batch_end(self, model, losses, batch, batch_idx)
         return losses
 
     def fit(self, batches, max_batches=None):

@@ -50,9 +50,23 @@ def ref_conv(mode, x, w, b):
 @pytest.mark.parametrize("mode,n,cin,cout,h,w", [
     (0, 2, 64, 128, 16, 16), (0, 1, 128, 256, 12, 20), (0, 2, 32, 64, 8, 8), (0, 1, 256, 32, 8, 16), (0, 2, 96, 128, 8, 16),
     (1, 2, 64, 64, 16, 16), (1, 1, 128, 128, 24, 8), (2, 2, 64, 64, 8, 8), (2, 1, 128, 128, 6, 10), (4, 2, 64, 192, 8, 8),
-    (4, 1, 256, 256, 16, 16), (4, 3, 32, 64, 4, 4)])
-def test_conv_bf16_fwd_bwd(hip_lib, mode, n, cin, cout, h, w):
+    (4, 1, 256, 256, 16, 16), (4, 3, 32, 64, 4, 4),
+    # the wide tile (16 x 16 pixels x 128 channels, LDS-DMA halo ring): whole tiles, ragged tiles in both directions, one / two / four
+    # 32-channel chunks, two output-channel blocks, forward and (Cin > 64) data gradient
+    (0, 2, 128, 128, 32, 32), (0, 1, 256, 256, 20, 36), (0, 1, 128, 256, 17, 16), (0, 3, 32, 128, 16, 48), (0, 1, 96, 192, 33, 18)])
+@pytest.mark.parametrize("wide", [0, 1], ids=["tile8x16", "tile16x16"])
+def test_conv_bf16_fwd_bwd(hip_lib, mode, n, cin, cout, h, w, wide):
     from odvae_amd import ops
+    if wide and not (mode == 0 and max(cin, cout) > 64 and h >= 16):
+        pytest.skip("shape never reaches the wide tile")
+    prev = hip_lib.odvae_conv_bf16_select_wide_tile(wide)
+    try:
+        _conv_bf16_fwd_bwd(ops, mode, n, cin, cout, h, w)
+    finally:
+        hip_lib.odvae_conv_bf16_select_wide_tile(max(prev, 0))
+
+
+def _conv_bf16_fwd_bwd(ops, mode, n, cin, cout, h, w):
     g = torch.Generator().manual_seed(mode * 1000 + cin + cout + h)
     k = 1 if mode == 4 else 3
     x = rb(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)

@@ -97,7 +97,16 @@ def _worker(rank, world, port, out_dir):
     net2(full_x[shard]).pow(2).mean().backward()
     red2.finish()
     g2 = torch.cat([p.grad.reshape(-1) for p in net2.parameters()]).clone()
-    torch.save({"synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
+    # bf16 gradient buckets (the exchange of the bf16 step): cast -> all-reduce -> back into the f32 gradients
+    net3 = TinyNet()
+    opt3 = torch.optim.SGD(net3.parameters(), lr=0.1)
+    red3 = GradReducer(opt3, bucket_mb=0.02, comm_dtype=torch.bfloat16)
+    red3.broadcast_parameters(net3)
+    red3.prepare_for_backward()
+    net3(full_x[shard]).pow(2).mean().backward()
+    red3.finish()
+    g3 = torch.cat([p.grad.reshape(-1) for p in net3.parameters()]).clone()
+    torch.save({"g3": g3, "sd3": net3.state_dict(), "nb3": len(red3.buckets), "order3": list(red3.launch_order), "synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
                 "global_step": model._global_step}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -132,3 +141,13 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     ref2(full_x).pow(2).mean().backward()
     want = torch.cat([p.grad.reshape(-1) for p in ref2.parameters()])
     assert torch.allclose(r0["g2"], want, atol=1e-6) and torch.equal(r0["g2"], r1["g2"])
+    # bf16 buckets: every bucket travelled, both ranks hold the same gradients, and they are the full-batch gradients up to the
+    # bf16 rounding of the two shard gradients (2^-8 each) and of their sum
+    ref3 = TinyNet()
+    ref3.load_state_dict(r0["sd3"])
+    ref3(full_x).pow(2).mean().backward()
+    want3 = torch.cat([p.grad.reshape(-1) for p in ref3.parameters()])
+    assert r0["nb3"] >= 2 and sorted(r0["order3"]) == list(range(r0["nb3"]))
+    assert torch.equal(r0["g3"], r1["g3"])
+    assert (r0["g3"] - want3).abs().max().item() <= 2.0 ** -6 * want3.abs().max().item()
+    assert not torch.equal(r0["g3"], want3)          # it really went through bf16

@@ -81,3 +81,20 @@ def test_perturbed_pose_reconstruction_matches_oracle(hip_lib):
     got = out["perturbed_pose_reconstruction_rgb"].cpu()
     assert (got - want).abs().max().item() <= 1e-3 * max(1.0, want.abs().max().item())
     assert (got - out["reconstructions_rgb"].cpu()).abs().max().item() > 1e-3      # it really is a different image
+
+
+def test_runner_with_yaml_callbacks_writes_image_grids(hip_lib, tmp_path):
+    """`-l <logdir>`: the callbacks of the untouched yaml (yaml:115-131) run behind the training loop; ImageLogger calls log_images on
+    the device at global steps 2, 4 (its power-of-two schedule; PL counts two optimizer steps per batch) and writes the three PNGs of
+    src/util/callbacks.py:141-160 per firing, max_images = 1 (yaml:119) -> a bare 64 x 64 image, values in the open range."""
+    import numpy as np
+    from PIL import Image
+    from odvae_amd import run
+    model = run.main(["-b", YAML, "--steps", "2", "--height", "64", "-l", str(tmp_path), "model.params.ddconfig.ch=32", "data.params.batch_size=2"])
+    assert model.training and model.global_step == 4
+    files = sorted(os.listdir(os.path.join(tmp_path, "images", "train")))
+    assert files == sorted("%s_gs-%06d_e-000000_b-%06d.png" % (k, gs, b) for gs, b in ((2, 0), (4, 1))
+                           for k in ("inputs_rgb", "reconstructions_rgb", "perturbed_pose_reconstruction_rgb")), files
+    img = np.asarray(Image.open(os.path.join(tmp_path, "images", "train", "inputs_rgb_gs-000004_e-000000_b-000001.png")))
+    assert img.shape == (64, 64, 3) and img.min() == 0 and img.max() >= 254      # _rescale maps the batch to [-1, 1]
+    assert "DeviceStatsMonitor.on_train_batch_end/allocated_bytes.all.current" in model.logged_metrics
