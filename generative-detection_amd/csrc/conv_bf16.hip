@@ -426,6 +426,176 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wide_kernel(ConvB p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// All operands through LDS (stride-1 3x3 convs with more than 64 output channels): block = 16 x 16 output pixels x 128 output
+// channels, 8 waves of 64 co x 64 px (2 x 2 MFMA tiles), 16 input channels per chunk.
+//
+// The lesson of the wide tile above: a wave's vector-memory operations complete in issue order, so a per-step weight load issued
+// behind the fetch of a later halo chunk waits out that fetch's HBM latency.  Here NO global load is waited for inside a chunk: the
+// chunk's weights (nine taps x four 32-channel tiles = 36 fragments of 1 KiB, which sit lane-linear in the pack exactly as an
+// LDS-DMA piece writes them) and its halo (18 x 18 pixels x 16 channels = 11 pieces) arrive by asm LDS-DMA in a ring of three 47 KB
+// stages, two chunks ahead; every MFMA operand is a ds_read_b128; one `s_waitcnt vmcnt(0)` + barrier per chunk (36 MFMAs per wave).
+// Halo image: [halo px][2 x 16 B], the half index XOR-ed with (px >> 3) & 1 so that sixteen consecutive pixels of a lane group cover
+// sixteen different 16-byte positions.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
+  constexpr int TAPS = 9, TH = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
+  constexpr int WPIECES = TAPS * 4, HPIECES = (HPIX * 2 + 63) / 64, PIECES = WPIECES + HPIECES;   // 36 + 11
+  constexpr unsigned STAGEB = PIECES * 1024, HALO_OFF = WPIECES * 1024;
+  constexpr int WCT = 2, WPT = 2;
+  extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
+  const unsigned lds0 = lds_addr_of(smem);
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave >> 2, wpx = wave & 3;
+
+  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int co0 = blockIdx.y * 128;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int esz = p.out_f32 ? 4 : 2;
+  const unsigned OOB = 0x7FFFFFF0u;
+  const int KT = p.CinP / 16, CT = p.CoutP / 32;
+  const int nchunks = KT;
+
+  // ---- fetch plan: piece j = wave + 8 k (k = 0 .. 5); j < 36: weight fragment (tap j / 4, channel tile j % 4), else halo piece j - 36 --
+  const i32x4_t xw = rsrc_words(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin, (unsigned)(p.Hi * p.Wi * p.Cin * 2));
+  const i32x4_t ww = rsrc_words(p.wpk, (unsigned)(TAPS * KT * CT * 1024));
+  unsigned hvoff[2];                 // this lane's source offsets of the wave's (up to) two halo pieces, chunk 0
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = wave + 8 * (4 + q);
+    const int slot = 64 * (j - WPIECES) + lane;
+    const int px = slot >> 1, half = (slot & 1) ^ ((px >> 3) & 1);
+    const int iy = iy0 + px / HW, ix = ix0 + px % HW;
+    const bool ok = j >= WPIECES && j < PIECES && px < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    hvoff[q] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * half) * 2) : OOB;
+  }
+  const unsigned lane16 = lane * 16;
+  auto issue = [&](int kt, unsigned stage) {
+    const unsigned st = lds0 + stage;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int j = wave + 8 * k;                     // wave-uniform
+      if (j < WPIECES) {
+        const int tap = j >> 2, ct = j & 3;
+        lds_dma16(ww, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + 1024u * j)),
+                  (unsigned)(((tap * KT + kt) * CT + co0 / 32 + ct) * 1024) + lane16);
+      } else if (j < PIECES) {
+        lds_dma16(xw, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + 1024u * j)), hvoff[k >= 4 ? k - 4 : 0] + (unsigned)(kt * 32));
+      }
+    }
+  };
+  issue(0, 0);
+  if (nchunks > 1) issue(1, STAGEB);
+
+  // this lane's pixel in each of its two pixel tiles (column of the MFMA result)
+  unsigned pixoff[WPT];
+  int hp0[WPT];
+#pragma unroll
+  for (int pt = 0; pt < WPT; ++pt) {
+    const int pm = (wpx * WPT + pt) * 32 + li;
+    const int pr = pm / TW, pc = pm % TW;
+    const int oy = oy0 + pr, ox = ox0 + pc;
+    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
+    hp0[pt] = pr * HW + pc;
+  }
+
+  // accumulators start at bias + residual: the epilogue is stores only
+  f32x16 acc[WCT][WPT];
+  {
+    const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) {
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.residual) {
+            const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
+            rv[0] = bf16_lo(v.x); rv[1] = bf16_hi(v.x); rv[2] = bf16_lo(v.y); rv[3] = bf16_hi(v.y);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ct][pt][4 * g + j] = bv[j] + rv[j];
+        }
+      }
+  }
+
+  // operand reads of step `tap` from the stage at LDS address sa: weight fragments are lane-linear, pixel fragments swizzled
+  const unsigned a_lane = (unsigned)(wco * WCT) * 1024u + lane16;
+  auto load_ab = [&](unsigned sa, int tap, bf16x8 (&a)[WCT], bf16x8 (&b)[WPT]) {
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(lds_ld128(sa + a_lane + (unsigned)((tap * 4 + ct) * 1024)));
+    const int toff = (tap / 3) * HW + (tap % 3);
+#pragma unroll
+    for (int pt = 0; pt < WPT; ++pt) {
+      const unsigned px = (unsigned)(hp0[pt] + toff);
+      b[pt] = frag_from_u32x4(lds_ld128(sa + HALO_OFF + px * 32u + ((((px >> 3) ^ (unsigned)h) & 1u) << 4)));
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned cur = 0, nxt = STAGEB, fre = 2 * STAGEB;
+  constexpr int RS = 3;                                 // steps in flight (operands of step s + 2 are requested before step s multiplies)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 2 < nchunks) issue(ch + 2, fre);           // the stage chunk ch - 1 left: its last reads ended before the barrier above
+    const unsigned sa = lds0 + cur;
+    bf16x8 abuf[RS][WCT], bbuf[RS][WPT];
+    load_ab(sa, 0, abuf[0], bbuf[0]);
+    load_ab(sa, 1, abuf[1], bbuf[1]);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (tap + 2 < TAPS) load_ab(sa, tap + 2, abuf[(tap + 2) % RS], bbuf[(tap + 2) % RS]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(abuf[tap % RS][ct], bbuf[tap % RS][pt], acc[ct][pt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    { const unsigned o = cur; cur = nxt; nxt = fre; fre = o; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: stores only ------------------------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      static_cast<char*>(p.y) + (int64_t)n * p.Ho * p.Wo * p.Cout * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
+#pragma unroll
+  for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int pt = 0; pt < WPT; ++pt) {
+        if (p.out_f32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ct][pt][4 * g + j]), yrsrc, off, 0, 0);
+          }
+        } else {
+          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+          u32x2 v;
+          v.x = pack_bf16x2(acc[ct][pt][4 * g + 0], acc[ct][pt][4 * g + 1]);
+          v.y = pack_bf16x2(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
+        }
+      }
+    }
+}
+
 // OIHW f32 (kh x kw = 3x3 or 1x1) -> bf16 fragment packs.
 //   fwd:   reduce over Cin, rows = Cout:   W[tap][co][ci]
 //   dgrad: reduce over Cout, rows = Cin:   W'[tap][ci][co] = w[co][ci][flip(tap)]   (MODE 0 / 4 data gradient; MODE 3 uses
@@ -490,9 +660,10 @@ static int g_wide_tile = -1;   // -1: not chosen yet (environment decides at the
 
 extern "C" {
 
-// 1: stride-1 3x3 convs with Cout > 64, Cin % 32 == 0, Ho >= 16 run on the wide tile (conv_bf16_wide_kernel); 0: on the 128-pixel tile
-// (default; ODVAE_CONV_BF16_WIDE2 presets it).  Returns the previous setting (-1 = environment not read yet).
-int odvae_conv_bf16_select_wide_tile(int on) { const int prev = g_wide_tile; g_wide_tile = on ? 1 : 0; return prev; }
+// Tile of the stride-1 3x3 convs with Cout > 64 and Ho >= 16: 0 = 8 x 16 pixels (conv_bf16_kernel), 1 = 16 x 16 with an LDS-DMA halo
+// ring and weights from L2 (conv_bf16_wide_kernel, Cin % 32 == 0), 2 = 16 x 16 with weights AND halo through LDS
+// (conv_bf16_lds_kernel, Cin % 16 == 0).  ODVAE_CONV_BF16_WIDE2 presets it.  Returns the previous setting (-1 = environment not read yet).
+int odvae_conv_bf16_select_wide_tile(int on) { const int prev = g_wide_tile; g_wide_tile = on < 0 ? 0 : (on > 2 ? 2 : on); return prev; }
 
 // reduction-channel padding (16 per MFMA k-step; the kernel walks chunks of 32 or 64) and output-channel padding of a pack
 int odvae_conv_bf16_reduce_pad(int c) { return c % 64 == 0 ? c : pad_to(c, 32); }
@@ -555,7 +726,20 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   // conv_bf16_kernel.  The structural fix is weights through LDS as well (no per-step global loads); DESIGN.md 9.
   if (g_wide_tile < 0) g_wide_tile = getenv("ODVAE_CONV_BF16_WIDE2") ? atoi(getenv("ODVAE_CONV_BF16_WIDE2")) : 0;
   const int wide2 = g_wide_tile;
-  if (mode == 0 && wide2 && Cout > 64 && Cin % 32 == 0 && Ho >= 16) {
+  if (mode == 0 && wide2 == 2 && Cout > 64 && Cin % 16 == 0 && Ho >= 16) {
+    p.tiles_y = ceil_div(Ho, 16);
+    constexpr int lds_bytes = 3 * 47 * 1024;
+    static bool once_l = false;
+    if (!once_l) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      once_l = true;
+    }
+    ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
+    hipLaunchKernelGGL(conv_bf16_lds_kernel, dim3(N * p.tiles_x * p.tiles_y, ceil_div(Cout, 128)), dim3(512), lds_bytes, st, p);
+    ODVAE_LAUNCH_CHECK("conv_bf16 (all-LDS tile)");
+    return ODVAE_OK;
+  }
+  if (mode == 0 && wide2 == 1 && Cout > 64 && Cin % 32 == 0 && Ho >= 16) {
     p.tiles_y = ceil_div(Ho, 16);
     constexpr int lds_bytes = 3 * 21 * 1024;
     static bool once = false;
