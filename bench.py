@@ -268,14 +268,14 @@ def main():
     model.train()
     if args.ckpt_decoder:
         model.decoder.activation_checkpoint = True
-    if args.bf16:
-        model.set_precision("bf16")   # bf16 activations on the bf16 MFMA kernels + fused attention; f32 master weights
+    # --bf16: the trainer's `precision: bf16` (yaml:139) -- bf16 activations on the bf16 MFMA kernels + fused attention, f32 master
+    # weights; with N > 1 the gradient buckets then travel as bf16 too (parallel.GradReducer)
     # steady state: past the very first optimizer step, whose total holds the pose terms only (`global_step >
     # encoder_pretrain_steps`, contperceptual.py:307) and would skip the decoder's backward pass -- every timed step does the
     # full forward + backward + optimizer work even with --warmup 0
     model._global_step = 1
     trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if args.gan else (0,),
-                      process_group=dist.group.WORLD if use_dist else None)
+                      process_group=dist.group.WORLD if use_dist else None, precision="bf16" if args.bf16 else None)
     batch = synthetic.make_batch(args.batch, args.res, seed=23 + rank)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}  # inputs resident in HBM
 

@@ -123,7 +123,12 @@ class AutoencoderKL(LightningModule):
         return self.decoder.conv_out.weight
 
     def to_rgb(self, x):
-        raise NotImplementedError("segmentation colorize path is not part of the OD-VAE hot path")
+        """Random fixed 1x1 projection of a C-channel map to three channels, rescaled to [-1, 1] over the batch
+        (src/models/autoencoder.py:438-443; [UPSTREAM] AutoencoderKL.to_rgb, used when `colorize_nlabels` is given).
+        `colorize` is a buffer drawn once, as in the reference."""
+        if not hasattr(self, "colorize"):
+            self.register_buffer("colorize", torch.randn(3, x.shape[1], 1, 1).to(x))
+        return ops.rescale_minmax(ops.conv1x1(x, self.colorize))
 
 
 class Autoencoder(AutoencoderKL):

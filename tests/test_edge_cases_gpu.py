@@ -109,3 +109,17 @@ def test_batch_of_one(hip_lib):
     from odvae_amd import synthetic
     model, ref = build_pair()
     _compare(model, ref, _batch([5]), synthetic.make_noise(1, 4, dropout_p=0.7, seed=24))
+
+
+def test_to_rgb_matches_reference_formula(hip_lib):
+    """to_rgb (src/models/autoencoder.py:438-443): a fixed random 1x1 projection to three channels, min-max rescaled over the batch."""
+    import torch.nn.functional as F
+    model, _ = build_pair()
+    x = torch.randn(2, 16, 12, 20, generator=torch.Generator().manual_seed(3)).to("cuda:0")
+    y = model.to_rgb(x)
+    w = model.colorize.detach().cpu()
+    assert tuple(w.shape) == (3, 16, 1, 1) and "colorize" in dict(model.named_buffers())
+    ref = F.conv2d(x.cpu(), w)
+    ref = 2.0 * (ref - ref.min()) / (ref.max() - ref.min()) - 1.0
+    assert tuple(y.shape) == (2, 3, 12, 20) and (y.cpu() - ref).abs().max().item() < 1e-5
+    assert torch.equal(model.to_rgb(x), y)           # the projection is drawn once
