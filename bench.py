@@ -353,7 +353,8 @@ def main():
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
             tfile = None
-            for cand in (("r02_bf16_conv_traffic.json",) if args.bf16 else ("r02_conv3x3_traffic.json", "r01_conv3x3_traffic.json")):
+            for cand in (("r03_bf16_conv_traffic.json", "r02_bf16_conv_traffic.json") if args.bf16
+                         else ("r03_conv3x3_traffic.json", "r02_conv3x3_traffic.json", "r01_conv3x3_traffic.json")):
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     tfile = cand
                     break

@@ -29,6 +29,14 @@ def main(path):
     print("| kernel | launches | total ms | avg us | % of busy |\n|---|---:|---:|---:|---:|")
     for k, v in by.most_common(40):
         print("| `%s` | %d | %.2f | %.1f | %.1f |" % (k, cnt[k], v, 1e3 * v / cnt[k], 100 * v / busy))
+    # where the idle time sits: the largest gaps between the end of one kernel and the start of the next
+    short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
+    gaps = sorted(((seg[i + 1][0] - seg[i][1]) / 1e3, short(seg[i][2]), short(seg[i + 1][2])) for i in range(len(seg) - 1))
+    big = [g for g in gaps if g[0] > 20.0]
+    print("\ngaps between consecutive kernels: %d over 20 us, %.2f ms in all; the ten largest:\n" % (len(big), sum(g[0] for g in big) / 1e3))
+    print("| gap us | after | before |\n|---:|---|---|")
+    for g in gaps[-10:][::-1]:
+        print("| %.0f | `%s` | `%s` |" % g)
 
 
 if __name__ == "__main__":
