@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wide_kernel(ConvB p) {
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
   constexpr int TAPS = 9, TH = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
-  constexpr int WPIECES = TAPS * 4, HPIECES = (HPIX * 2 + 63) / 64, PIECES = WPIECES + HPIECES;   // 36 + 11
+  constexpr int WPIECES = TAPS * 4, HPIECES = (HPIX * 2 + 63) / 64, PIECES = WPIECES + HPIECES + 1;   // 36 + 11 + one dummy: six per wave
   constexpr unsigned STAGEB = PIECES * 1024, HALO_OFF = WPIECES * 1024;
   constexpr int WCT = 2, WPT = 2;
   extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
     const int slot = 64 * (j - WPIECES) + lane;
     const int px = slot >> 1, half = (slot & 1) ^ ((px >> 3) & 1);
     const int iy = iy0 + px / HW, ix = ix0 + px % HW;
-    const bool ok = j >= WPIECES && j < PIECES && px < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    const bool ok = j >= WPIECES && px < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;   // piece 47 is all out of range: zeros
     hvoff[q] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * half) * 2) : OOB;
   }
   const unsigned lane16 = lane * 16;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
         const int tap = j >> 2, ct = j & 3;
         lds_dma16(ww, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + 1024u * j)),
                   (unsigned)(((tap * KT + kt) * CT + co0 / 32 + ct) * 1024) + lane16);
-      } else if (j < PIECES) {
+      } else {      // (the last piece only pads every wave's batch to six pieces: the counted wait below needs one number)
         lds_dma16(xw, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + 1024u * j)), hvoff[k >= 4 ? k - 4 : 0] + (unsigned)(kt * 32));
       }
     }
@@ -565,7 +565,10 @@ __global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     { const unsigned o = cur; cur = nxt; nxt = fre; fre = o; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The batch issued at the top of THIS chunk is for the chunk after next: only the previous batch has to have landed now.  A fetch
+    // gets two chunk periods (HBM latency is longer than one).
+    if (ch + 2 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -728,7 +731,7 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   const int wide2 = g_wide_tile;
   if (mode == 0 && wide2 == 2 && Cout > 64 && Cin % 16 == 0 && Ho >= 16) {
     p.tiles_y = ceil_div(Ho, 16);
-    constexpr int lds_bytes = 3 * 47 * 1024;
+    constexpr int lds_bytes = 3 * 48 * 1024;
     static bool once_l = false;
     if (!once_l) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);

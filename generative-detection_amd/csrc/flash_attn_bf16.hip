@@ -509,6 +509,9 @@ __global__ __launch_bounds__(256) void flash_dkv_kernel(FlashP p) {
 // Blocks of one image share an XCD (one L2 streams its q / k / v / dO rows once).
 // ------------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// wait until at most N of this wave's vector-memory operations are outstanding (N = the pieces of the newest fetch batch: a batch is
+// given two periods to land -- it is issued for the tile after next -- and only the batch before it has to be complete at a barrier)
+template <int N> __device__ __forceinline__ void wait_vm_all_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #ifndef ODVAE_FLASH_PAIR_PRIO
 #define ODVAE_FLASH_PAIR_PRIO 1
 #endif
@@ -526,7 +529,9 @@ struct PairGeom {
   static constexpr int TILEB = 32 * ROWB;         // one 32-row tile
   static constexpr int PIECES = TILEB / 1024;     // LDS-DMA wave-instructions per tile (8 or 16)
   static constexpr int STAGEB = 2 * TILEB + 512;  // two tiles + two 256-byte row-constant slots
-  static constexpr int NSTAGE = 3;
+  static constexpr int BATCH = 2 * (PIECES / 8);  // LDS-DMA pieces a wave issues per tile pair
+  static constexpr int NSTAGE = 3;                // dK/dV ring; the producer / consumer kernels (dQ, forward) run four stages
+  static constexpr int NSTAGE_PC = 4;
 };
 
 __device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
     }
     if (role == 0) probabilities(nxt, xsel ^ (4 * XB));
     const unsigned t = cur; cur = nxt; nxt = fre; fre = t;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm_all_but<0>();     // tile j + 2 is read in the next period already (first product): its fetch gets this one period
     if (!(ODVAE_FLASH_ABL & 2)) __syncthreads();
   }
   if (kok) {
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
   constexpr unsigned XB = 2048;                            // one pair's dS^T tile as two packed bf16 fragments: [2][64 lanes][16 bytes]
   extern __shared__ __attribute__((aligned(1024))) char smem_c[];
   const unsigned smem = lds_addr_of(smem_c);
-  const unsigned xbuf = smem + G::NSTAGE * G::STAGEB;     // [2 buffers][4 pairs][XB]
+  const unsigned xbuf = smem + G::NSTAGE_PC * G::STAGEB;  // [2 buffers][4 pairs][XB]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, pair = wave & 3;             // role 0 = A (S^T, dP^T, dS^T), 1 = B (dQ^T)
@@ -774,7 +779,8 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
   if (ntiles > 1) issue(1, G::STAGEB);
   const unsigned xl = xbuf + pair * XB + lane * 16;
   // period t (0 .. ntiles): the producer multiplies tile t (stage cur), the consumer tile t - 1 (stage prv); tile t + 1 lands in nxt
-  unsigned prv = 2 * G::STAGEB, cur = 0, nxt = G::STAGEB;
+  // four stages: tile t + 2 is fetched during period t (into the stage tile t - 2 left) and has two periods to land
+  unsigned prv = 3 * G::STAGEB, cur = 0, nxt = G::STAGEB, nn = 2 * G::STAGEB;
 
   if (role == 0) {
     // ---- producer ----
@@ -790,7 +796,8 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t <= ntiles; ++t) {
-      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      const bool fetch = t + 2 < ntiles;
+      if (fetch) issue(t + 2, nn);
       if (t < ntiles) {
         const unsigned kr = rowl + cur;
         f32x16 sa, da;
@@ -822,8 +829,8 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
         lds_st128(xw, __builtin_bit_cast(u32x4, frag_from_acc(sa, 0)));
         lds_st128(xw + 1024, __builtin_bit_cast(u32x4, frag_from_acc(sa, 1)));
       }
-      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = nn; nn = o; }
+      if (fetch) wait_vm_all_but<G::BATCH>(); else wait_vm_all_but<0>();     // the batch just issued stays in flight
       __syncthreads();
     }
   } else {
@@ -839,7 +846,8 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t <= ntiles; ++t) {
-      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      const bool fetch = t + 2 < ntiles;
+      if (fetch) issue(t + 2, nn);
       if (t >= 1) {
         const unsigned xr = xl + ((t - 1) & 1) * 4 * XB;
         constexpr int RING = 8, NM = D / 16;      // dQ^T += K^T dS^T; transposed fragments RING MFMAs ahead
@@ -858,8 +866,8 @@ __global__ __launch_bounds__(512) void flash_dq_pair_kernel(FlashP p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = nn; nn = o; }
+      if (fetch) wait_vm_all_but<G::BATCH>(); else wait_vm_all_but<0>();     // the batch just issued stays in flight
       __syncthreads();
     }
     if (qok) {
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
   constexpr unsigned XB = 2048 + 256;                      // one pair's P^T tile (two packed bf16 fragments) + 64 rescale factors
   extern __shared__ __attribute__((aligned(1024))) char smem_c[];
   const unsigned smem = lds_addr_of(smem_c);
-  const unsigned xbuf = smem + G::NSTAGE * G::STAGEB;     // [2 buffers][4 pairs][XB]
+  const unsigned xbuf = smem + G::NSTAGE_PC * G::STAGEB;  // [2 buffers][4 pairs][XB]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, pair = wave & 3;             // role 0 = A (S^T, softmax), 1 = B (O^T)
@@ -913,7 +921,8 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
   if (ntiles > 1) issue(1, G::STAGEB);
   const unsigned xl = xbuf + pair * XB + lane * 16;        // fragment slot of this lane
   const unsigned al = xbuf + pair * XB + 2048 + lane * 4;  // rescale-factor slot of this lane
-  unsigned prv = 2 * G::STAGEB, cur = 0, nxt = G::STAGEB;
+  // four stages: tile t + 2 is fetched during period t (into the stage tile t - 2 left) and has two periods to land
+  unsigned prv = 3 * G::STAGEB, cur = 0, nxt = G::STAGEB, nn = 2 * G::STAGEB;
 
   if (role == 0) {
     // ---- producer ----
@@ -926,7 +935,8 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t <= ntiles; ++t) {
-      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      const bool fetch = t + 2 < ntiles;
+      if (fetch) issue(t + 2, nn);
       if (t < ntiles) {
         const unsigned kr = rowl + cur;
         f32x16 st;
@@ -969,8 +979,8 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
         lds_st128(xl + xs + 1024, __builtin_bit_cast(u32x4, frag_from_acc(st, 1)));
         *(__attribute__((address_space(3))) float*)(uintptr_t)(al + xs) = alpha;
       }
-      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = nn; nn = o; }
+      if (fetch) wait_vm_all_but<G::BATCH>(); else wait_vm_all_but<0>();     // the batch just issued stays in flight
       __syncthreads();
     }
     l += __shfl_xor(l, 32, 64);
@@ -990,7 +1000,8 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t <= ntiles; ++t) {
-      if (t >= 1 && t + 1 < ntiles) issue(t + 1, nxt);
+      const bool fetch = t + 2 < ntiles;
+      if (fetch) issue(t + 2, nn);
       if (t >= 1) {
         const unsigned xs = ((t - 1) & 1) * 4 * XB;
         constexpr int RING = 8, NM = D / 16;
@@ -1016,8 +1027,8 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      { const unsigned o = prv; prv = cur; cur = nxt; nxt = o; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { const unsigned o = prv; prv = cur; cur = nxt; nxt = nn; nn = o; }
+      if (fetch) wait_vm_all_but<G::BATCH>(); else wait_vm_all_but<0>();     // the batch just issued stays in flight
       __syncthreads();
     }
     __syncthreads();
@@ -1037,9 +1048,9 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
   }
 }
 
-template <int D> constexpr int fwd_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * (2048 + 256); }
+template <int D> constexpr int fwd_pair_lds() { return PairGeom<D>::NSTAGE_PC * PairGeom<D>::STAGEB + 2 * 4 * (2048 + 256); }
 template <int D> constexpr int dkv_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 4096; }
-template <int D> constexpr int dq_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
+template <int D> constexpr int dq_pair_lds() { return PairGeom<D>::NSTAGE_PC * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
 
 template <typename K>
 void launch_dyn(K kernel, dim3 grid, int lds_bytes, hipStream_t st, const FlashP& p, int threads = 256) {
