@@ -194,7 +194,11 @@ def ref_attention(qkv):
 
 
 @pytest.mark.parametrize("n,c,h,w", [(2, 64, 16, 16), (2, 128, 4, 4), (1, 256, 32, 32), (2, 512, 8, 8), (1, 64, 6, 6), (3, 128, 5, 9),
-                                     (1, 256, 64, 64)])
+                                     (1, 256, 64, 64),
+                                     # wave-pair kernels (C = 128 / 256) on token counts that are multiples of neither the 32-row tile
+                                     # nor the 128-row block, fewer tiles than ring stages, and a batch that is a multiple of 8 (the
+                                     # XCD-grouped block order)
+                                     (1, 256, 5, 9), (2, 256, 12, 11), (1, 256, 50, 82), (8, 128, 6, 7), (16, 256, 3, 3)])
 def test_flash_attention_bf16(hip_lib, n, c, h, w):
     """Fused attention forward + backward vs the materialised-scores formula in f32 (T = 16 ... 4096, head dim 64 ... 512, token
     counts that are not multiples of the 32-key / 128-query tiles)."""
