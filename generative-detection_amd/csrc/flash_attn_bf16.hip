@@ -516,6 +516,16 @@ template <int N> __device__ __forceinline__ void wait_vm_all_but() { asm volatil
 #define ODVAE_FLASH_PAIR_PRIO 1
 #endif
 __device__ __forceinline__ bool flash_pair_prio() { return ODVAE_FLASH_PAIR_PRIO != 0; }
+// -DODVAE_FLASH_STAMPS: s_memtime stamps in the dK/dV pair kernel (diagnostic build; tools/flash_stamps.py reads them with
+// odvae_flash_debug_stamps).  Per role (A, B): cycles summed over the periods of block 0, pair 0, of the sections
+//   0 tile fetch issue | 1 ring fill + (B) dS arithmetic | 2 second product (16 MFMAs) | 3 first product (16 MFMAs) | 4 (A) probabilities |
+//   5 vmcnt wait | 6 barrier
+#ifdef ODVAE_FLASH_STAMPS
+__device__ unsigned long long g_flash_stamps[2][8];
+#define FSTAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sacc_[k] += now_ - last_; last_ = now_; } while (0)   /* scalar registers only: no memory traffic inside the loop */
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
 // timing-only ablation builds (tools/ab_build.py ... -DODVAE_FLASH_ABL=mask; results are WRONG): 1 = no tile fetch inside the loop,
 // 2 = no barrier inside the loop, 4 = no softmax / dS arithmetic, 8 = no second product, 16 = no first product
 #ifndef ODVAE_FLASH_ABL
@@ -536,19 +546,31 @@ struct PairGeom {
 
 __device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-// this wave's share of one tile: pieces wave, wave + 8 (, ...) of the [32][D] image of rows row0.. / columns col0.. of a [T][ld] matrix
+// One LDS-DMA piece (1 KiB = RPP rows of 2 D bytes) of the [32][D] image of rows row0.. / columns col0.. of a [T][ld] matrix: piece j holds
+// tile rows j RPP .. j RPP + RPP - 1; lane (r_in = lane / CPR, chp = lane % CPR) fills chunk position chp of row j RPP + r_in with source
+// chunk chp ^ swz16(row).  The row part of the source offset is scalar arithmetic; per lane it is a shift, an OR, an XOR and an add
+// (issuing a piece used to carry fourteen vector instructions, a 32-bit vector multiply among them: 160-180 cycles per piece, a fifth of
+// a dK/dV period -- in-kernel stamps, tools/flash_stamps.py).  full = the tile lies inside the matrix (no per-lane range check).
+template <int D>
+__device__ __forceinline__ void dma_piece(i32x4_t rsrc, unsigned lds_tile, int j, int row0, int T, int ld, int col0, bool full, int lane) {
+  using G = PairGeom<D>;
+  constexpr int RPP = 64 / G::CPR;                        // rows per piece: 2 (D = 256) or 4 (D = 128)
+  const unsigned r_in = (unsigned)lane / G::CPR, chp = (unsigned)lane % G::CPR;
+  // swz16(j RPP + r_in): RPP = 2: ((2 j & 2) | r_in) << 2 | (j >> 1) & 3;  RPP = 4: r_in << 2 | j & 3
+  const unsigned s0 = RPP == 2 ? ((((unsigned)j << 1) & 2u) << 2) | (((unsigned)j >> 1) & 3u) : ((unsigned)j & 3u);
+  const unsigned ch = chp ^ (s0 | (r_in << 2));
+  const unsigned rowbase = (unsigned)(((row0 + j * RPP) * ld + col0) * 2);          // scalar
+  unsigned voff = rowbase + r_in * (unsigned)(ld * 2) + (ch << 4);
+  if (!full) voff = row0 + j * RPP + (int)r_in < T ? voff : 0x7FFFFFF0u;
+  lds_dma16(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_tile + 1024u * j)), voff);
+}
+// this wave's share of one tile under the even split: pieces wave, wave + 8 (, ...)
 template <int D>
 __device__ __forceinline__ void dma_tile(i32x4_t rsrc, unsigned lds_tile, int row0, int T, int ld, int col0, int wave, int lane) {
   using G = PairGeom<D>;
+  const bool full = row0 + 32 <= T;
 #pragma unroll
-  for (int k = 0; k < G::PIECES / 8; ++k) {
-    const int j = wave + 8 * k;
-    const int slot = 64 * j + lane;                       // 16-byte slot of the LDS image this lane fills
-    const int row = slot / G::CPR, chp = slot % G::CPR;
-    const int ch = chp ^ swz16(row);                      // the chunk that belongs there
-    const unsigned voff = row0 + row < T ? (unsigned)(((row0 + row) * ld + col0 + 8 * ch) * 2) : 0x7FFFFFF0u;
-    lds_dma16(rsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_tile + 1024u * j)), voff);
-  }
+  for (int k = 0; k < G::PIECES / 8; ++k) dma_piece<D>(rsrc, lds_tile, wave + 8 * k, row0, T, ld, col0, full, lane);
 }
 // 32 per-row f32 constants (lse2 / delta of rows row0..) into a 256-byte slot: lanes 32..63 write zeros behind them
 __device__ __forceinline__ void dma_rowconst(i32x4_t rsrc, unsigned lds_slot, int row0, int T, int lane) {
@@ -596,16 +618,18 @@ __device__ __forceinline__ void pair_block_coords(int N, int QB, int& n, int& qb
 template <int D>
 __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
   using G = PairGeom<D>;
-  constexpr unsigned XB = 4096;                            // one pair's P tile, f32, [4 register quads][64 lanes][16 bytes]
+  constexpr unsigned XB = 2048;                            // one pair's P tile as two packed bf16 fragments: [2][64 lanes][16 bytes]
+  constexpr int NST = 4;                                   // tile stages: a fetch is issued three tiles ahead and has two periods to land
   extern __shared__ __attribute__((aligned(1024))) char smem_c[];
   const unsigned smem = lds_addr_of(smem_c);
-  const unsigned xbuf = smem + G::NSTAGE * G::STAGEB;     // [2 buffers][4 pairs][XB]
+  const unsigned xbuf = smem + NST * G::STAGEB;           // [2 buffers][4 pairs][XB]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, pair = wave & 3;             // role 0 = A (S, P, dV), 1 = B (dP, dS, dK)
   // Waves w and w + 4 (a pair) share a SIMD.  A runs ahead: its MFMAs take the matrix pipe first, B's vector work (dS) hides under
   // them at the start of a period and B's MFMAs fill the pipe while A computes the next tile's probabilities at its end.
-  if (role == 0 && flash_pair_prio()) __builtin_amdgcn_s_setprio(2);
+  if (ODVAE_FLASH_PAIR_PRIO == 1 && role == 0) __builtin_amdgcn_s_setprio(2);
+  if (ODVAE_FLASH_PAIR_PRIO == 2 && role == 1) __builtin_amdgcn_s_setprio(2);
   const int QB = (p.T + 127) / 128;
   int n, kb;
   pair_block_coords(p.N, QB, n, kb);
@@ -623,15 +647,35 @@ __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
   const bool kok = key0 + li < p.T;
   const int ntiles = (p.T + 31) / 32;
 
-  auto issue = [&](int t, unsigned stage) {   // tile t (query rows 32 t ..): Q rows, dO rows, lse2, delta
+  // Fetch duty (in-kernel stamps, tools/flash_stamps.py): a piece costs ~100-150 cycles of the issuing wave's time; issued by every wave
+  // at the top of a period -- the first form -- all four SIMDs sat without an MFMA for ~800 of 3 600 cycles, and B (dS arithmetic in front
+  // of its MFMAs, its MFMAs behind A's on the shared pipe) is the long pole while A waits a quarter of the period at the barrier.  So the A
+  // waves alone fetch -- PIECES / 2 tile pieces each, waves 0 and 1 the two row-constant pieces as well -- and they do it BETWEEN their
+  // MFMAs, one piece per four, where the cost lands on the wave with slack and B's MFMAs keep the pipe busy meanwhile.
+  constexpr int NPA = G::PIECES / 2;
+  auto fetch_piece = [&](int t, unsigned stage, int q) {     // A wave: its q-th piece (q < NPA; q == NPA: row constants) of tile t
     const unsigned st = smem + stage;
-    dma_tile<D>(wqkv, st, 32 * t, p.T, C3, 0, wave, lane);
-    dma_tile<D>(wdo, st + G::TILEB, 32 * t, p.T, p.C, 0, wave, lane);
-    if (wave == 0) dma_rowconst(wl, st + 2 * G::TILEB, 32 * t, p.T, lane);
-    if (wave == 1) dma_rowconst(wd, st + 2 * G::TILEB + 256, 32 * t, p.T, lane);
+    int lane_v = lane;                                       // opaque copy: the source offsets are recomputed, not kept in registers
+    asm volatile("" : "+v"(lane_v));
+    const bool full = 32 * t + 32 <= p.T;
+    if (q < NPA) {
+      const int g = wave + 4 * q;                            // g in [0, 2 PIECES): Q tile pieces, then dO tile pieces
+      if (g < G::PIECES) dma_piece<D>(wqkv, st, g, 32 * t, p.T, C3, 0, full, lane_v);
+      else dma_piece<D>(wdo, st + G::TILEB, g - G::PIECES, 32 * t, p.T, p.C, 0, full, lane_v);
+    } else {
+      if (wave == 0) dma_rowconst(wl, st + 2 * G::TILEB, 32 * t, p.T, lane_v);
+      if (wave == 1) dma_rowconst(wd, st + 2 * G::TILEB + 256, 32 * t, p.T, lane_v);
+    }
+  };
+  auto issue = [&](int t, unsigned stage) {                 // prologue: a whole tile at once
+    if (role == 0) {
+#pragma unroll
+      for (int q = 0; q <= NPA; ++q) fetch_piece(t, stage, q);
+    }
   };
   issue(0, 0);
   if (ntiles > 1) issue(1, G::STAGEB);
+  if (ntiles > 2) issue(2, 2 * G::STAGEB);
 
   // B fragments of this pair's 32 keys: K for role A, V for role B
   bf16x8 bf[D / 16];
@@ -669,18 +713,22 @@ __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
   auto probabilities = [&](unsigned stage, unsigned xsel) {
     if (ODVAE_FLASH_ABL & 4) { pf[0] = frag_from_acc(s1, 0); pf[1] = frag_from_acc(s1, 1); return; }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = lds_ld128f(constl + stage + 32 * g);
-      f32x4 pv;
+    for (int gp = 0; gp < 2; ++gp) {     // two row-constant reads in flight at a time (two LDS latencies per tile, not four; four do not fit the registers)
+      const f32x4 la = lds_ld128f(constl + stage + 64 * gp), lb = lds_ld128f(constl + stage + 64 * gp + 32);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pv[e] = fast_exp2(fmaf(s1[4 * g + e], c, -l4[e])); s1[4 * g + e] = pv[e]; }
-      lds_st128f(xl + xsel + 1024 * g, pv);
+      for (int e = 0; e < 4; ++e) {
+        s1[8 * gp + e] = fast_exp2(fmaf(s1[8 * gp + e], c, -la[e]));
+        s1[8 * gp + 4 + e] = fast_exp2(fmaf(s1[8 * gp + 4 + e], c, -lb[e]));
+      }
     }
     pf[0] = frag_from_acc(s1, 0);
     pf[1] = frag_from_acc(s1, 1);
+    // B takes the bf16 fragments A multiplies with (its dS = P (dP - delta) scale is rounded to bf16 once more anyway)
+    lds_st128(xl + xsel, __builtin_bit_cast(u32x4, pf[0]));
+    lds_st128(xl + xsel + 1024, __builtin_bit_cast(u32x4, pf[1]));
   };
 
-  unsigned cur = 0, nxt = G::STAGEB, fre = 2 * G::STAGEB;    // stages of tiles j, j + 1, j + 2 (= the one tile j - 1 leaves)
+  unsigned cur = 0, nxt = G::STAGEB, nx2 = 2 * G::STAGEB, fre = 3 * G::STAGEB;    // stages of tiles j, j + 1, j + 2, j + 3 (= the one tile j - 1 leaves)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   first_product_only(0);
@@ -692,8 +740,14 @@ __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
   // a wave waits out an LDS latency once per period, not once per product.  In the last period the first product runs on a stale
   // stage and its result is dropped.
   constexpr int NB = D / 16, NA = D / 16, RING = D >= 256 ? 4 : 6;   // D = 256 sits at 256 registers with four fragments in flight
+#ifdef ODVAE_FLASH_STAMPS
+  const bool stamp_on = blockIdx.x == 0 && pair == 0;
+  unsigned long long sacc_[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int j = 0; j < ntiles; ++j) {
-    if (j + 2 < ntiles && !(ODVAE_FLASH_ABL & 1)) issue(j + 2, fre);  // its last (transposed) reads ended before the barrier above
+    const bool fetching = role == 0 && j + 3 < ntiles && !(ODVAE_FLASH_ABL & 1);   // into the stage tile j - 1 left (free since the barrier above)
+    FSTAMP(0);
     const unsigned xsel = (j & 1) * 4 * XB;
     const unsigned rv = rowl + nxt;
     bf16x8 ring[RING];
@@ -702,18 +756,27 @@ __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
     for (int i = 0; i < RING; ++i) ring[i] = fetch(i);
     if (role == 1 && !(ODVAE_FLASH_ABL & 4)) {   // dS = P (dP - delta) scale from A's probabilities (the ring's first reads are in flight)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 pv = lds_ld128f(xl + xsel + 1024 * g);
-        const f32x4 d4 = lds_ld128f(constl + cur + 256 + 32 * g);
+      for (int sfr = 0; sfr < 2; ++sfr) {      // per fragment: its eight probabilities (one read) and the two row-constant quads, in flight together
+        // P in fragment order: dword k of fragment s holds P of registers 8 s + 2 k (low half) and 8 s + 2 k + 1 (high half)
+        const u32x4 pw = lds_ld128(xl + xsel + 1024 * sfr);
+        const f32x4 da = lds_ld128f(constl + cur + 256 + 64 * sfr), db = lds_ld128f(constl + cur + 256 + 64 * sfr + 32);
+        const float pv[8] = {bf16_lo(pw.x), bf16_hi(pw.x), bf16_lo(pw.y), bf16_hi(pw.y), bf16_lo(pw.z), bf16_hi(pw.z), bf16_lo(pw.w), bf16_hi(pw.w)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s1[4 * g + e] = pv[e] * fmaf(s1[4 * g + e], p.scale, -d4[e] * p.scale);
+        for (int e = 0; e < 4; ++e) {
+          s1[8 * sfr + e] = pv[e] * fmaf(s1[8 * sfr + e], p.scale, -da[e] * p.scale);
+          s1[8 * sfr + 4 + e] = pv[4 + e] * fmaf(s1[8 * sfr + 4 + e], p.scale, -db[e] * p.scale);
+        }
       }
       pf[0] = frag_from_acc(s1, 0);
       pf[1] = frag_from_acc(s1, 1);
     }
+    FSTAMP(1);
 #pragma unroll
     for (int i = 0; i < NB + NA; ++i) {
       __builtin_amdgcn_sched_barrier(0);
+#ifdef ODVAE_FLASH_STAMPS
+      if (i == NB) FSTAMP(2);
+#endif
       if (i < NB) {
         if (!(ODVAE_FLASH_ABL & 8)) acc[i >> 1] = mfma_bf16(ring[i % RING], pf[i & 1], acc[i >> 1]);
       } else {
@@ -724,13 +787,27 @@ __global__ __launch_bounds__(512) void flash_dkv_pair_kernel(FlashP p) {
         if (!(ODVAE_FLASH_ABL & 16)) s1 = mfma_bf16(ring[i % RING], bf[i - NB], s1);
       }
       if (i + RING < NB + NA) ring[i % RING] = fetch(i + RING);
+      if ((i & 3) == 1 && (i >> 2) < NPA && fetching) fetch_piece(j + 3, fre, i >> 2);      // A: one fetch piece per four MFMAs
+      if (i == 3 && fetching) fetch_piece(j + 3, fre, NPA);                                  // (waves 0, 1: the row constants)
       __builtin_amdgcn_sched_barrier(0);
     }
+    FSTAMP(3);
     if (role == 0) probabilities(nxt, xsel ^ (4 * XB));
-    const unsigned t = cur; cur = nxt; nxt = fre; fre = t;
-    wait_vm_all_but<0>();     // tile j + 2 is read in the next period already (first product): its fetch gets this one period
+    FSTAMP(4);
+    const unsigned t = cur; cur = nxt; nxt = nx2; nx2 = fre; fre = t;
+    // tile j + 2 is read in the next period (first product) and was fetched in the previous one: everything but the batch just issued
+    // has to have landed (waves 0 and 1 carry one row-constant piece more)
+    if (!fetching) wait_vm_all_but<0>();          // (B waves have no vector-memory operations in the loop at all)
+    else if (wave < 2) wait_vm_all_but<NPA + 1>();
+    else wait_vm_all_but<NPA>();
+    FSTAMP(5);
     if (!(ODVAE_FLASH_ABL & 2)) __syncthreads();
+    FSTAMP(6);
   }
+#ifdef ODVAE_FLASH_STAMPS
+  if (stamp_on && lane == 0)
+    for (int k = 0; k < 7; ++k) g_flash_stamps[role][k] += sacc_[k];
+#endif
   if (kok) {
     bf16_t* row = p.out + ((int64_t)n * p.T + key0 + li) * C3 + (role == 0 ? 2 * p.C : p.C);
 #pragma unroll
@@ -1049,7 +1126,7 @@ __global__ __launch_bounds__(512) void flash_fwd_pair_kernel(FlashP p) {
 }
 
 template <int D> constexpr int fwd_pair_lds() { return PairGeom<D>::NSTAGE_PC * PairGeom<D>::STAGEB + 2 * 4 * (2048 + 256); }
-template <int D> constexpr int dkv_pair_lds() { return PairGeom<D>::NSTAGE * PairGeom<D>::STAGEB + 2 * 4 * 4096; }
+template <int D> constexpr int dkv_pair_lds() { return 4 * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
 template <int D> constexpr int dq_pair_lds() { return PairGeom<D>::NSTAGE_PC * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
 
 template <typename K>
@@ -1071,6 +1148,15 @@ bool shape_ok(int N, int T, int C) {
 }
 
 }  // namespace
+
+#ifdef ODVAE_FLASH_STAMPS
+extern "C" int odvae_flash_debug_stamps(unsigned long long* out16, int reset) {
+  (void)hipDeviceSynchronize();
+  if (out16) (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_flash_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_flash_stamps), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 extern "C" {
 
