@@ -106,8 +106,13 @@ class PoseEncoderSpatialVAE(nn.Module):
             z = z.unsqueeze(0)
         b = z.size(0)
         if z.is_cuda:
-            # the grid is the same for every row: one row of coord_linear, broadcast over the batch
-            h = ops.linear_act(self.x.to(z).reshape(1, self.x_dim), self.coord_linear.weight, self.coord_linear.bias)
+            # the grid is the same for every row: one row of coord_linear, broadcast over the batch.  Its device copy is made once:
+            # `self.x` is a host tensor (a plain attribute, as in the reference), and `.to(device)` of pageable host memory blocks the
+            # host until the stream has drained -- one full pipeline stall per forward (found with torch.cuda.set_sync_debug_mode).
+            key = (z.device, z.dtype)
+            if getattr(self, "_x_dev_key", None) != key:
+                self._x_dev, self._x_dev_key = self.x.to(z).reshape(1, self.x_dim), key
+            h = ops.linear_act(self._x_dev, self.coord_linear.weight, self.coord_linear.bias)
             h_z = ops.linear_act(z, self.latent_linear.weight)
         else:
             grid = self.x.to(z).expand(b, self.num_coords, self.in_dim).reshape(b, self.x_dim)

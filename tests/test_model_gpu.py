@@ -261,3 +261,36 @@ def test_config5_geometry_512_matches_oracle(hip_lib):
             continue
         e = (g.cpu().double() - rg.double()).abs().max().item() / max(rg.abs().max().item(), 1e-3 * scale)
         assert e < 5e-3, "param grad %s rel err %.3e" % (name, e)
+
+
+@pytest.mark.parametrize("gan", [False, True], ids=["rec+KL", "gan+lpips"])
+def test_training_batch_never_synchronises_the_host(hip_lib, gan):
+    """A training batch (both optimizers with the GAN on) issues into the stream without a single host synchronisation
+    (torch.cuda.set_sync_debug_mode("error") raises at the first one): the host may run a whole step ahead of the device.  Round 3 found
+    one with it -- the pose encoder's coordinate grid, a pageable host tensor, was copied to the device in every forward."""
+    from odvae_amd import synthetic
+    from odvae_amd.trainer import Trainer
+    kw = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if gan else {}
+    torch.manual_seed(23)
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32, **kw).to("cuda:0").train()
+    model._global_step = 1
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if gan else (0,))
+    batch = synthetic.make_batch(2, 64, seed=23)
+    batch = {k: (v.to("cuda:0") if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def step(i):
+        b = dict(batch)
+        b["pose_6d"] = batch["pose_6d"].clone()
+        return trainer.training_batch(b, i)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(2):          # first steps build packs, workspaces and the staging ring
+            step(i)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            losses = step(2)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    assert all(torch.isfinite(l).all() for l in losses)
