@@ -263,8 +263,8 @@ def test_config5_geometry_512_matches_oracle(hip_lib):
         assert e < 5e-3, "param grad %s rel err %.3e" % (name, e)
 
 
-@pytest.mark.parametrize("gan", [False, True], ids=["rec+KL", "gan+lpips"])
-def test_training_batch_never_synchronises_the_host(hip_lib, gan):
+@pytest.mark.parametrize("gan,precision", [(False, None), (True, None), (False, "bf16")], ids=["rec+KL", "gan+lpips", "rec+KL-bf16"])
+def test_training_batch_never_synchronises_the_host(hip_lib, gan, precision):
     """A training batch (both optimizers with the GAN on) issues into the stream without a single host synchronisation
     (torch.cuda.set_sync_debug_mode("error") raises at the first one): the host may run a whole step ahead of the device.  Round 3 found
     one with it -- the pose encoder's coordinate grid, a pageable host tensor, was copied to the device in every forward."""
@@ -274,7 +274,7 @@ def test_training_batch_never_synchronises_the_host(hip_lib, gan):
     torch.manual_seed(23)
     model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32, **kw).to("cuda:0").train()
     model._global_step = 1
-    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if gan else (0,))
+    trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if gan else (0,), precision=precision)
     batch = synthetic.make_batch(2, 64, seed=23)
     batch = {k: (v.to("cuda:0") if torch.is_tensor(v) else v) for k, v in batch.items()}
 
