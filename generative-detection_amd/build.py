@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.path.join(HERE, "libodvae_hip.so")
-HIP_SOURCES = ["gemm_f32.hip", "conv3x3_f32.hip", "conv3x3_wino_f32.hip", "conv3x3_wgrad_f32.hip", "conv3x3_wgrad_wino_f32.hip", "groupnorm.hip", "elementwise.hip",
+HIP_SOURCES = ["gemm_f32.hip", "conv3x3_f32.hip", "conv3x3_wino_f32.hip", "conv3x3_wino4_f32.hip", "conv3x3_wgrad_f32.hip", "conv3x3_wgrad_wino_f32.hip", "groupnorm.hip", "elementwise.hip",
                "gan_f32.hip", "lpips_f32.hip", "patch_u8.hip", "pose_f32.hip", "linear_f32.hip",
                "conv_bf16.hip", "conv_wgrad_bf16.hip", "flash_attn_bf16.hip", "bf16_ops.hip"]
 CXX_SOURCES = ["runtime.cpp"]

@@ -92,6 +92,16 @@ __device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_dst, unsign
   (void)rsrc; (void)lds_dst; (void)voff;
 #endif
 }
+// the same with a scalar byte offset added to every lane's address (a per-chunk step costs no vector instruction)
+__device__ __forceinline__ void lds_dma16_s(i32x4_t rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
+#else
+  (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
 __device__ __forceinline__ void lds_dma4(i32x4_t rsrc, unsigned lds_dst, unsigned voff) {
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned keep;

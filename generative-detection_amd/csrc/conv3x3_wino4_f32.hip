@@ -1,0 +1,379 @@
+// Stride-1 3x3 convolution by Winograd F(4x4, 3x3), NHWC f32, fused transforms, gfx950.
+//
+// Same contract as conv3x3_wino_f32.hip (the ResnetBlock convs of [UPSTREAM] ldm/modules/diffusionmodules/model.py and
+// their data gradients) with 36 instead of 64 multiply-adds per 4x4 output pixels and (ci, co) -- 4x fewer than the
+// direct form, 1.78x fewer than F(2x2, 3x3):
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        per 4x4 output tile, d = its 6x6 input patch
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// i.e. thirty-six independent [tiles x Cin] x [Cin x Cout] products M[xi] = V[xi] U[xi] on the f32 MFMA, U = G g G^T packed
+// once per weight update.  The arithmetic is f32 throughout; the interpolation points 0, +-1, +-2 cost accuracy against
+// F(2x2): measured max deviation from an f64 direct convolution 4e-6 of max|y| at Cin = 128 (direct f32: 2e-7).
+//
+// Block = 8 waves on 16 x 32 output pixels = 32 tiles (4 x 8) x 64 output channels: the 36 x 32 x 64 accumulators are 58 %
+// of the CU's register file, which is what bounds the block (with 128 output channels they do not fit at all).  Wave
+// (g, ct) owns xi = 9g .. 9g+8 for output channels 32 ct .. 32 ct + 31.  Per 8-channel chunk: the input halo (18 x 34 px) comes
+// by LDS-DMA straight into LDS (no registers), in two planes (one per channel quad) whose rows are stored 4-way
+// interleaved in x (x' = 9 (x & 3) + (x >> 2)) with a pitch of 38 slots: the 6x6 patches of eight neighbouring tiles then
+// read as 128 contiguous bytes and those of the tile row below land on the other half of the banks -- every LDS access of
+// the transform is conflict-free.  The input transform is split over the eight waves by ROWS of B^T d (rows {1,2}, {3,4}
+// share their partial sums; 0 and 5 stand alone), one pair role and one single role per SIMD, two float channels per lane
+// (packed f32 math); V is [xi][quad][tile][4], so an A fragment is 1 KB contiguous.  One barrier per chunk; V and the halo
+// are double-buffered.  The output transform goes through LDS one tile row at a time (36 values per (tile, co) -> 16 pixels).
+#include "bf16_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 16, TW = 32;            // output pixels per block
+constexpr int TXN = TW / 4;                // 8 tiles per tile row, 4 tile rows
+constexpr int KC = 8;                      // channels per chunk
+constexpr int BN = 64;                     // output channels per block
+constexpr int HROWS = TH + 2;              // 18 halo rows
+constexpr int ROWP = 38;                   // 16-byte slots per halo row of one plane (36 used)
+constexpr int PLANE = HROWS * ROWP;        // 684
+constexpr int HALO_SLOTS = 2 * PLANE;      // 1368 slots = 21.4 KB
+constexpr int HALO_DMA_PER_WAVE = 3;       // 24 LDS-DMA instructions of 1 KB per chunk (the last two carry no data)
+constexpr unsigned HALO_B = 8 * HALO_DMA_PER_WAVE * 1024;   // 24 576
+constexpr unsigned V_B = 36 * 1024;        // [36 xi][2 quads][32 tiles][4 floats]
+constexpr unsigned LDS_B = 2 * HALO_B + 2 * V_B;            // 122 880
+constexpr unsigned OOB = 0x7FFFFFF0u;
+
+struct Wino4Params {
+  const float* x;         // [N][H][W][Cin]
+  const float* upk;       // [36][CinP/4][CoutP][4]
+  const float* bias;      // [Cout] or null
+  const float* residual;  // [N][H][W][Cout] or null
+  float* y;               // [N][H][W][Cout]
+  int N, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, act, xcd;
+};
+
+__device__ __forceinline__ f32x2 lds_ld64f(unsigned a) { return *(const __attribute__((address_space(3))) f32x2*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st64f(unsigned a, f32x2 v) { *(__attribute__((address_space(3))) f32x2*)(uintptr_t)a = v; }
+__device__ __forceinline__ float lds_ld32f(unsigned a) { return *(const __attribute__((address_space(3))) float*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st32f(unsigned a, float v) { *(__attribute__((address_space(3))) float*)(uintptr_t)a = v; }
+template <int N> __device__ __forceinline__ void wait_vm_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// one row of (B^T d) times B: six values t[0..5] along x -> the six V entries of that row, stored 1 KB apart
+__device__ __forceinline__ void column_pass_store(const f32x2 (&t)[6], unsigned dst) {
+  const f32x2 a = t[4] - 4.f * t[2], b = t[3] - 4.f * t[1];
+  const f32x2 a2 = t[4] - t[2], e = t[3] - t[1];
+  lds_st64f(dst + 0 * 1024, 4.f * t[0] + (t[4] - 5.f * t[2]));
+  lds_st64f(dst + 1 * 1024, a + b);
+  lds_st64f(dst + 2 * 1024, a - b);
+  lds_st64f(dst + 3 * 1024, a2 + 2.f * e);
+  lds_st64f(dst + 4 * 1024, a2 - 2.f * e);
+  lds_st64f(dst + 5 * 1024, 4.f * t[1] + (t[5] - 5.f * t[3]));
+}
+
+__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
+  extern __shared__ __attribute__((aligned(16))) float dsmem[];
+  const unsigned lds0 = lds_addr_of(dsmem);
+  const unsigned halo0 = lds0, v0 = lds0 + 2 * HALO_B;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int g = wave >> 1, ct = wave & 1;          // MFMA role: xi group, co tile
+  int t = p.xcd ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- halo by LDS-DMA: wave w issues instructions w, w + 8, w + 16 of a chunk (64 slots of 16 bytes each) ----
+  const i32x4_t xrs = rsrc_words(p.x + (int64_t)n * p.H * p.W * p.Cin, (unsigned)(p.H * p.W * p.Cin) * 4u);
+  unsigned hvoff[HALO_DMA_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < HALO_DMA_PER_WAVE; ++k) {
+    const int s = (wave + 8 * k) * 64 + lane;
+    const int quad = s >= PLANE ? 1 : 0;
+    const int rem = s - quad * PLANE;
+    const int hr = rem / ROWP, xp = rem - hr * ROWP;
+    const int hx = 4 * (xp % 9) + xp / 9;
+    const int iy = oy0 - 1 + hr, ix = ox0 - 1 + hx;
+    const bool ok = s < HALO_SLOTS && xp < 36 && hx < TW + 2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    hvoff[k] = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + 4 * quad) * 4) : OOB;
+  }
+  auto dma_halo = [&](int ch, int stage) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(ch * (KC * 4));
+#pragma unroll
+    for (int k = 0; k < HALO_DMA_PER_WAVE; ++k)
+      lds_dma16_s(xrs, (unsigned)__builtin_amdgcn_readfirstlane((int)(halo0 + stage * HALO_B + (wave + 8 * k) * 1024u)), hvoff[k], soff);
+  };
+
+  // ---- input transform: wave -> (rows of B^T d, half of the tile rows); lane -> (channel pair, tile) ----
+  const int role = wave >> 1, hh = wave & 1;       // 0: rows 1,2   1: rows 3,4   2: row 5   3: row 0
+  const int pb = lane & 1, ttx = (lane >> 1) & 7, ty4 = 2 * hh + ((lane >> 4) & 1), tquad = lane >> 5;
+  const unsigned t_rd = (unsigned)((tquad * PLANE + 4 * ty4 * ROWP + ttx) * 16 + pb * 8);
+  const unsigned t_wr = (unsigned)(tquad * 512 + (ty4 * 8 + ttx) * 16 + pb * 8);
+  constexpr unsigned RB = ROWP * 16;
+#define ODVAE_W4_D(r, c) lds_ld64f(rd + (r) * RB + ((((c) & 3) * 9 + ((c) >> 2)) * 16))
+  auto transform = [&](unsigned hsrc, unsigned vdst) {
+    const unsigned rd = hsrc + t_rd, wr = vdst + t_wr;
+    if (role == 0) {
+      f32x2 t1[6], t2[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const f32x2 d1 = ODVAE_W4_D(1, c), d2 = ODVAE_W4_D(2, c), d3 = ODVAE_W4_D(3, c), d4 = ODVAE_W4_D(4, c);
+        const f32x2 a = d4 - 4.f * d2, b = d3 - 4.f * d1;
+        t1[c] = a + b; t2[c] = a - b;
+      }
+      column_pass_store(t1, wr + 6 * 1024);
+      column_pass_store(t2, wr + 12 * 1024);
+    } else if (role == 1) {
+      f32x2 t3[6], t4[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const f32x2 d1 = ODVAE_W4_D(1, c), d2 = ODVAE_W4_D(2, c), d3 = ODVAE_W4_D(3, c), d4 = ODVAE_W4_D(4, c);
+        const f32x2 a = d4 - d2, e = d3 - d1;
+        t3[c] = a + 2.f * e; t4[c] = a - 2.f * e;
+      }
+      column_pass_store(t3, wr + 18 * 1024);
+      column_pass_store(t4, wr + 24 * 1024);
+    } else if (role == 2) {
+      f32x2 t5[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const f32x2 d1 = ODVAE_W4_D(1, c), d3 = ODVAE_W4_D(3, c), d5 = ODVAE_W4_D(5, c);
+        t5[c] = 4.f * d1 + (d5 - 5.f * d3);
+      }
+      column_pass_store(t5, wr + 30 * 1024);
+    } else {
+      f32x2 t0[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const f32x2 d0 = ODVAE_W4_D(0, c), d2 = ODVAE_W4_D(2, c), d4 = ODVAE_W4_D(4, c);
+        t0[c] = 4.f * d0 + (d4 - 5.f * d2);
+      }
+      column_pass_store(t0, wr);
+    }
+  };
+#undef ODVAE_W4_D
+
+  // ---- weight fragments: buffer loads with a scalar (xi, chunk) offset, as in the F(2x2) kernel ----
+  const int QT = p.CinP / 4;
+  const int nchunks = p.CinP / KC;
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.upk), 0, 36 * p.CinP * p.CoutP * 4, 0x00020000);
+  const unsigned b_voff = (unsigned)((h * p.CoutP + n0 + ct * 32 + li) * 16);
+  const int b_row = p.CoutP * 16;
+  auto load_b = [&](int ch, int j) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((9 * g + j) * QT + 2 * ch) * b_row);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ursrc, b_voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float4 b[9];
+  dma_halo(0, 0);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) b[j] = load_b(0, j);
+  if (nchunks > 1) { dma_halo(1, 1); wait_vm_but<9 + HALO_DMA_PER_WAVE>(); }
+  else wait_vm_but<9>();
+  __syncthreads();
+  transform(halo0, v0);
+  wait_vm_but<0>();
+  __syncthreads();
+
+  const unsigned a_off = (unsigned)(9 * g * 1024 + lane * 16);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const unsigned Vc = v0 + (ch & 1) * V_B + a_off;
+    const bool more = ch + 1 < nchunks;
+    if (ch + 2 < nchunks) dma_halo(ch + 2, ch & 1);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const f32x4 a = lds_ld128f(Vc + j * 1024);
+      acc[j] = mfma32(a.x, b[j].x, acc[j]);
+      acc[j] = mfma32(a.y, b[j].y, acc[j]);
+      acc[j] = mfma32(a.z, b[j].z, acc[j]);
+      acc[j] = mfma32(a.w, b[j].w, acc[j]);
+      if (more) b[j] = load_b(ch + 1, j);
+      if (j == 4 && more) transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
+    }
+    if (ch + 2 < nchunks) wait_vm_but<9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
+    __syncthreads();
+  }
+
+  // ---- output transform, one tile row (= accumulator registers 4 rq .. 4 rq + 3) at a time through X[ct][xi][e][lane] ----
+  const unsigned X0 = v0;
+  const int img_bytes = p.H * p.W * p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, p.residual ? img_bytes : 0, 0x00020000);
+  const bool relu = p.act != 0;
+  const int ct2 = wave & 1, e2 = wave >> 1;        // the (co tile, register) this thread finishes in every pass
+  const int co = n0 + ct2 * 32 + li;
+  const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  const int cstep = p.Cout * 4, rstep = p.W * p.Cout * 4;
+  const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane) * 4);
+  const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane) * 4);
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds_st32f(x_wr + (j * 4 + e) * 256, acc[j][4 * rq + e]);
+    // element (register 4 rq + e2, lane) is tile (row rq, column 4 h + e2): a 4x4 pixel block of one output channel
+    const int py = oy0 + 4 * rq, px = ox0 + 4 * (4 * h + e2);
+    const unsigned base = (py < p.H && px < p.W && co < p.Cout) ? (unsigned)(((py * p.W + px) * p.Cout + co) * 4) : OOB;
+    float seed[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        seed[a][c] = bv + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, base, a * rstep + c * cstep, 0));
+    __syncthreads();
+    float tt[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float m[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) m[j] = lds_ld32f(x_rd + (6 * i + j) * 1024);
+      const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+      tt[i][0] = m[0] + s1 + s2;
+      tt[i][1] = d1 + 2.f * d2;
+      tt[i][2] = s1 + 4.f * s2;
+      tt[i][3] = d1 + 8.f * d2 + m[5];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s1 = tt[1][c] + tt[2][c], d1 = tt[1][c] - tt[2][c], s2 = tt[3][c] + tt[4][c], d2 = tt[3][c] - tt[4][c];
+      float yv[4];
+      yv[0] = tt[0][c] + s1 + s2 + seed[0][c];
+      yv[1] = d1 + 2.f * d2 + seed[1][c];
+      yv[2] = s1 + 4.f * s2 + seed[2][c];
+      yv[3] = d1 + 8.f * d2 + tt[5][c] + seed[3][c];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(yv[a], 0.f) : yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
+    }
+    if (rq < 3) __syncthreads();     // X is rewritten by the next pass
+  }
+}
+
+// U[xi = 6a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles.  One thread per
+// (co, ci) pair; padding entries of the packs are zero-filled by the launcher beforehand.
+__global__ void conv3x3_pack_wino4_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                          float* __restrict__ fwd, int CinP_f, int CoutP_f,
+                                          float* __restrict__ dgr, int CoutP_d, int CinP_d) {
+  const int64_t pairs = (int64_t)Cout * Cin;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
+    const float* gp = w + ((int64_t)co * Cin + ci) * 9;
+    float gg[3][3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gg[k / 3][k % 3] = gp[k];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float* dst = pass == 0 ? fwd : dgr;
+      if (!dst) continue;
+      // G x = (x0/4, -(x0+x1+x2)/6, -(x0-x1+x2)/6, x0/24 + x1/12 + x2/6, x0/24 - x1/12 + x2/6, x2)
+      float tv[6][3], u[6][6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float x0 = pass == 0 ? gg[0][c] : gg[2][2 - c], x1 = pass == 0 ? gg[1][c] : gg[1][2 - c],
+                    x2 = pass == 0 ? gg[2][c] : gg[0][2 - c];
+        const float e = x0 + x2;
+        tv[0][c] = 0.25f * x0;
+        tv[1][c] = -(e + x1) * (1.f / 6.f);
+        tv[2][c] = -(e - x1) * (1.f / 6.f);
+        const float f = x0 * (1.f / 24.f) + x2 * (1.f / 6.f);
+        tv[3][c] = f + x1 * (1.f / 12.f);
+        tv[4][c] = f - x1 * (1.f / 12.f);
+        tv[5][c] = x2;
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const float x0 = tv[a][0], x1 = tv[a][1], x2 = tv[a][2];
+        const float e = x0 + x2;
+        u[a][0] = 0.25f * x0;
+        u[a][1] = -(e + x1) * (1.f / 6.f);
+        u[a][2] = -(e - x1) * (1.f / 6.f);
+        const float f = x0 * (1.f / 24.f) + x2 * (1.f / 6.f);
+        u[a][3] = f + x1 * (1.f / 12.f);
+        u[a][4] = f - x1 * (1.f / 12.f);
+        u[a][5] = x2;
+      }
+      const int red = pass == 0 ? ci : co, out = pass == 0 ? co : ci;
+      const int redP = pass == 0 ? CinP_f : CoutP_d, outP = pass == 0 ? CoutP_f : CinP_d;
+#pragma unroll
+      for (int xi = 0; xi < 36; ++xi)
+        dst[(((int64_t)xi * (redP / 4) + red / 4) * outP + out) * 4 + (red & 3)] = u[xi / 6][xi % 6];
+    }
+  }
+}
+
+constexpr int round_up_i(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+extern "C" {
+
+// pack sizes: reduction axis padded to 8, output axis to 64
+int odvae_conv3x3_wino4_reduce_pad(int c_reduce) { return round_up_i(c_reduce, KC); }
+int odvae_conv3x3_wino4_out_pad(int c_out) { return round_up_i(c_out, BN); }
+size_t odvae_conv3x3_wino4_pack_floats(int c_reduce, int c_out) {
+  return (size_t)36 * odvae_conv3x3_wino4_reduce_pad(c_reduce) * odvae_conv3x3_wino4_out_pad(c_out);
+}
+// shapes the F(4x4) kernel takes (forward: reduce over Cin; the data gradient swaps the roles, so both must qualify)
+int odvae_conv3x3_wino4_supported(int H, int W, int Cin, int Cout) {
+  return H % 4 == 0 && W % 4 == 0 && H >= TH && W >= TW && Cin % KC == 0 && Cout % KC == 0 && Cin >= 32 && Cout >= 32;
+}
+
+int odvae_conv3x3_pack_wino4_f32(const float* w, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream) {
+  ODVAE_CHECK_ARG(w && Cout > 0 && Cin > 0, "conv3x3_pack_wino4: bad arguments");
+  const int CinP_f = odvae_conv3x3_wino4_reduce_pad(Cin), CoutP_f = odvae_conv3x3_wino4_out_pad(Cout);
+  const int CoutP_d = odvae_conv3x3_wino4_reduce_pad(Cout), CinP_d = odvae_conv3x3_wino4_out_pad(Cin);
+  if (!fwd_pack && !dgrad_pack) return ODVAE_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (fwd_pack && (CinP_f != Cin || CoutP_f != Cout)) {
+    if (hipMemsetAsync(fwd_pack, 0, (size_t)36 * CinP_f * CoutP_f * sizeof(float), st) != hipSuccess) { odvae_set_error("conv3x3_pack_wino4: memset failed"); return ODVAE_ERR_HIP; }
+  }
+  if (dgrad_pack && (CoutP_d != Cout || CinP_d != Cin)) {
+    if (hipMemsetAsync(dgrad_pack, 0, (size_t)36 * CoutP_d * CinP_d * sizeof(float), st) != hipSuccess) { odvae_set_error("conv3x3_pack_wino4: memset failed"); return ODVAE_ERR_HIP; }
+  }
+  const int blocks = (int)std::min<int64_t>(ceil_div64((int64_t)Cout * Cin, 256), 2048);
+  hipLaunchKernelGGL(conv3x3_pack_wino4_kernel, dim3(blocks), dim3(256), 0, st,
+                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d);
+  ODVAE_LAUNCH_CHECK("conv3x3_pack_wino4");
+  return ODVAE_OK;
+}
+
+// y = act(conv3x3_stride1_pad1(x) (+bias) (+residual)); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino4_f32.
+int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                            const float* bias, const float* residual, float* y, int act, void* stream) {
+  ODVAE_CHECK_ARG(x && upk && y, "conv3x3_wino4: null operand");
+  ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino4: empty shape");
+  ODVAE_CHECK_ARG(H % 4 == 0 && W % 4 == 0 && Cin % KC == 0, "conv3x3_wino4: needs H, W in multiples of 4 and Cin %% 8 == 0 (H=%d W=%d Cin=%d)", H, W, Cin);
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)upk & 15) == 0, "conv3x3_wino4: x/upk must be 16-byte aligned");
+  ODVAE_CHECK_ARG((int64_t)H * W * Cin * 4 < 0x7FFFFFF0ll && ((int64_t)(H + 3) * W + 3) * Cout * 4 < 0x7FFFFFF0ll,
+                  "conv3x3_wino4: one input / output image must stay below 2 GiB");
+  Wino4Params p;
+  p.x = x; p.upk = upk; p.bias = bias; p.residual = residual; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.CinP = odvae_conv3x3_wino4_reduce_pad(Cin); p.CoutP = odvae_conv3x3_wino4_out_pad(Cout);
+  p.tiles_x = ceil_div(W, TW); p.tiles_y = ceil_div(H, TH); p.act = act;
+  ODVAE_CHECK_ARG((int64_t)36 * p.CinP * p.CoutP * 4 < 0x7FFFFFF0ll, "conv3x3_wino4: pack too large");
+  const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
+  ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino4: too many tiles");
+  static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
+  p.xcd = xcd ? 1 : 0;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_B);
+  if (e != hipSuccess) {
+    odvae_set_error("conv3x3_wino4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return ODVAE_ERR_HIP;
+  }
+  hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(512), LDS_B, static_cast<hipStream_t>(stream), p);
+  ODVAE_LAUNCH_CHECK("conv3x3_wino4");
+  return ODVAE_OK;
+}
+
+}  // extern "C"

@@ -33,6 +33,12 @@ PROTOTYPES = {
     "odvae_conv3x3_wino_pack_floats": (_Z, [_I, _I]),
     "odvae_conv3x3_pack_wino_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "odvae_conv3x3_wino_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "odvae_conv3x3_wino4_reduce_pad": (_I, [_I]),
+    "odvae_conv3x3_wino4_out_pad": (_I, [_I]),
+    "odvae_conv3x3_wino4_pack_floats": (_Z, [_I, _I]),
+    "odvae_conv3x3_wino4_supported": (_I, [_I, _I, _I, _I]),
+    "odvae_conv3x3_pack_wino4_f32": (_I, [_P, _I, _I, _P, _P, _P]),
+    "odvae_conv3x3_wino4_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),

@@ -152,14 +152,14 @@ def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False, up=False):
         dgr = torch.empty(L.odvae_conv_bf16_pack_elems(cout, cin, taps), dtype=BF16, device=w.device) if want_dgrad else None
         _lib.check(L.odvae_conv_pack_bf16(w.data_ptr(), cout, cin, taps, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv_pack_bf16")
         return fwd, dgr
-    floats = (L.odvae_conv3x3_wino_pack_floats if up == "wino" else
+    floats = (L.odvae_conv3x3_wino_pack_floats if up == "wino" else L.odvae_conv3x3_wino4_pack_floats if up == "wino4" else
               L.odvae_conv3x3_up_pack_floats if up else L.odvae_conv3x3_pack_floats)
     fwd = dgr = None
     if want_fwd:
         fwd = torch.empty(floats(cin, cout), dtype=torch.float32, device=w.device)
     if want_dgrad:
         dgr = torch.empty(floats(cout, cin), dtype=torch.float32, device=w.device)
-    pack = (L.odvae_conv3x3_pack_wino_f32 if up == "wino" else
+    pack = (L.odvae_conv3x3_pack_wino_f32 if up == "wino" else L.odvae_conv3x3_pack_wino4_f32 if up == "wino4" else
             L.odvae_conv3x3_pack_up_f32 if up else L.odvae_conv3x3_pack_f32)
     _lib.check(pack(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv3x3_pack")
     return fwd, dgr
@@ -219,16 +219,26 @@ def _wino_ok(h, w, cin, cout):
     return WINOGRAD and h % 2 == 0 and w % 2 == 0 and cin % 4 == 0 and cout % 4 == 0 and cin >= 16 and cout >= 16
 
 
-def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0):
+# F(4x4, 3x3) (conv3x3_wino4_f32.hip) where the shape allows: 36 products per 4x4 tile instead of 64.  ODVAE_CONV_WINOGRAD4=0/1.
+WINOGRAD4 = os.environ.get("ODVAE_CONV_WINOGRAD4", "0") == "1"
+
+
+def _wino4_ok(h, w, cin, cout):
+    return WINOGRAD and WINOGRAD4 and bool(_L().odvae_conv3x3_wino4_supported(h, w, cin, cout))
+
+
+def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False):
     L = _L()
     n, _, h, w = x.shape
     y = _new_cl(n, cout, h, w, x)
     tag = KERNEL_EVENTS.begin() if cout > 32 else None
-    _lib.check(L.odvae_conv3x3_wino_f32(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
-                                        y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino")
+    fn = L.odvae_conv3x3_wino4_f32 if f4 else L.odvae_conv3x3_wino_f32
+    _lib.check(fn(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                  y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino4" if f4 else "conv3x3_wino")
+    # issued multiply-adds per output pixel and (ci, co): F(2x2,3x3) 16 per 2x2 tile = 4, F(4x4,3x3) 36 per 4x4 tile = 2.25
     KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
                       4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
-                      issued=2.0 * 4 * cin * cout * n * h * w)   # F(2x2,3x3): 16 products per 2x2 tile = 4 per pixel
+                      issued=2.0 * (2.25 if f4 else 4.0) * cin * cout * n * h * w)
     return y
 
 
@@ -242,11 +252,11 @@ class _Conv3x3(Function):
         cout, cin = weight.shape[0], weight.shape[1]
         up = mode == 2 and UPCONV_BY_PARITY
         if mode == 0 and _wino_ok(x.shape[2], x.shape[3], cin, cout):
-            up = "wino"
+            up = "wino4" if _wino4_ok(x.shape[2], x.shape[3], cin, cout) else "wino"
         fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), up)  # both packs in one launch
         b = bias.detach().contiguous() if bias is not None else None
-        if up == "wino":
-            y = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
+        if up in ("wino", "wino4"):
+            y = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, act=1 if relu else 0, f4=up == "wino4")
         else:
             y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
         ctx.mode, ctx.up = mode, up
@@ -273,8 +283,8 @@ class _Conv3x3(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             _, dgr = pack_conv3x3(weight, False, True, ctx.up)
-            if ctx.up == "wino":
-                dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None)
+            if ctx.up in ("wino", "wino4"):
+                dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=ctx.up == "wino4")
             elif mode == 0:
                 dx = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)
             elif mode == 1:

@@ -84,6 +84,19 @@ int odvae_conv3x3_pack_wino_f32(const float* w_oihw, int Cout, int Cin, float* f
 int odvae_conv3x3_wino_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
                            const float* bias, const float* residual, float* y, int act /* 0 none, 1 ReLU */, void* stream);
 
+/* ---- conv3x3_wino4_f32.hip: the same convolution by Winograd F(4x4, 3x3): 4x fewer multiply-adds than the direct form
+ * (1.78x fewer than F(2x2)), f32 throughout; the wider interpolation points cost accuracy (max deviation from an f64 direct
+ * convolution ~4e-6 of max|y| at Cin = 128, F(2x2) / direct f32: 2e-7).  Packs: [36][reduce_pad/4][out_pad][4] floats.
+ * Needs H, W in multiples of 4 and Cin % 8 == 0; `supported` names the shapes the step routes here (forward and data
+ * gradient both qualify). */
+int odvae_conv3x3_wino4_reduce_pad(int c_reduce);
+int odvae_conv3x3_wino4_out_pad(int c_out);
+size_t odvae_conv3x3_wino4_pack_floats(int c_reduce, int c_out);
+int odvae_conv3x3_wino4_supported(int H, int W, int Cin, int Cout);
+int odvae_conv3x3_pack_wino4_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
+int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                            const float* bias, const float* residual, float* y, int act /* 0 none, 1 ReLU */, void* stream);
+
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
  * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)
  * dw is OIHW [Cout][Cin][3][3], overwritten; dbias [Cout] or NULL. */
