@@ -183,20 +183,29 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   wait_vm_but<0>();
   __syncthreads();
 
+  // Loop body per xi: the A fragment of xi+1 is requested before the four MFMAs of xi, the weight fragment of xi is re-requested for
+  // the next chunk right behind them (unconditionally: past the last chunk it reloads the current one, which nobody reads).  The
+  // two waves of a SIMD run their share of the input transform at different points of the chunk (after xi 2 / after xi 6), so one
+  // of them always has MFMAs to issue while the other waits on LDS.
   const unsigned a_off = (unsigned)(9 * g * 1024 + lane * 16);
+  const int t_at = wave < 4 ? 2 : 6;
   for (int ch = 0; ch < nchunks; ++ch) {
     const unsigned Vc = v0 + (ch & 1) * V_B + a_off;
     const bool more = ch + 1 < nchunks;
+    const int chn = more ? ch + 1 : ch;
     if (ch + 2 < nchunks) dma_halo(ch + 2, ch & 1);
+    f32x4 a = lds_ld128f(Vc);
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const f32x4 a = lds_ld128f(Vc + j * 1024);
+      f32x4 an = a;
+      if (j < 8) an = lds_ld128f(Vc + (j + 1) * 1024);
       acc[j] = mfma32(a.x, b[j].x, acc[j]);
       acc[j] = mfma32(a.y, b[j].y, acc[j]);
       acc[j] = mfma32(a.z, b[j].z, acc[j]);
       acc[j] = mfma32(a.w, b[j].w, acc[j]);
-      if (more) b[j] = load_b(ch + 1, j);
-      if (j == 4 && more) transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
+      b[j] = load_b(chn, j);
+      a = an;
+      if ((j == 2 || j == 6) && j == t_at && more) transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
     }
     if (ch + 2 < nchunks) wait_vm_but<9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
     __syncthreads();
