@@ -49,12 +49,19 @@ struct Wino4Params {
   const float* residual;  // [N][H][W][Cout] or null
   float* y;               // [N][H][W][Cout]
   int N, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, act, xcd;
+  int persist;            // 1: 1-D grid of one block per CU, every block walks a sequence of tiles of one output-channel block
 };
 
 __device__ __forceinline__ f32x2 lds_ld64f(unsigned a) { return *(const __attribute__((address_space(3))) f32x2*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_st64f(unsigned a, f32x2 v) { *(__attribute__((address_space(3))) f32x2*)(uintptr_t)a = v; }
 __device__ __forceinline__ float lds_ld32f(unsigned a) { return *(const __attribute__((address_space(3))) float*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_st32f(unsigned a, float v) { *(__attribute__((address_space(3))) float*)(uintptr_t)a = v; }
+// -DODVAE_W4_ABL=<bits>: timing-only ablation builds (results are wrong): 1 no output transform, 2 no input transform in the loop,
+// 4 no weight refills, 8 no A-fragment reads, 16 no halo DMA in the loop, 32 no wait for the DMA at the end of a chunk, 64 no barrier,
+// 128 epilogue without the stores, 256 without the LDS exchange, 512 without its barriers
+#ifndef ODVAE_W4_ABL
+#define ODVAE_W4_ABL 0
+#endif
 template <int N> __device__ __forceinline__ void wait_vm_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // one row of (B^T d) times B: six values t[0..5] along x -> the six V entries of that row, stored 1 KB apart
@@ -78,26 +85,44 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
   const int g = wave >> 1, ct = wave & 1;          // MFMA role: xi group, co tile
-  int t = p.xcd ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int n0 = blockIdx.y * BN;
+  // Tile sequence of this block.  Not persistent: the one tile blockIdx.x names, output-channel block blockIdx.y.  Persistent (1-D
+  // grid of G blocks, G % (8 ny) == 0): block b works on co block (b >> 3) % ny and on tiles i_b, i_b + TL, ... of the
+  // XCD-contiguous order, TL = G / ny, i_b % 8 == b % 8 (the XCD the block runs on) -- the scheme of the F(2x2) kernel.
+  const int total_tiles = p.tiles_x * p.tiles_y * p.N;
+  const int ny = p.CoutP / BN;
+  const int TL = p.persist ? (int)gridDim.x / ny : 0;
+  const int yblk = p.persist ? ((int)blockIdx.x >> 3) % ny : (int)blockIdx.y;
+  int s_cur = p.persist ? ((int)blockIdx.x & 7) + 8 * (((int)blockIdx.x >> 3) / ny) : (int)blockIdx.x;
+  struct Tile { int oy0, ox0, n; };
+  auto decode = [&](int sidx) {
+    int t = (p.persist || p.xcd) ? xcd_contiguous(sidx, p.persist ? total_tiles : (int)gridDim.x) : sidx;
+    Tile T;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; T.n = t / p.tiles_y;
+    T.oy0 = ty * TH; T.ox0 = tx * TW;
+    return T;
+  };
+  Tile cur = decode(s_cur);
+  const int n0 = yblk * BN;
 
   // ---- halo by LDS-DMA: wave w issues instructions w, w + 8, w + 16 of a chunk (64 slots of 16 bytes each) ----
-  const i32x4_t xrs = rsrc_words(p.x + (int64_t)n * p.H * p.W * p.Cin, (unsigned)(p.H * p.W * p.Cin) * 4u);
+  i32x4_t xrs;
   unsigned hvoff[HALO_DMA_PER_WAVE];
+  auto set_halo = [&](const Tile& T) {
+    xrs = rsrc_words(p.x + (int64_t)T.n * p.H * p.W * p.Cin, (unsigned)(p.H * p.W * p.Cin) * 4u);
 #pragma unroll
-  for (int k = 0; k < HALO_DMA_PER_WAVE; ++k) {
-    const int s = (wave + 8 * k) * 64 + lane;
-    const int quad = s >= PLANE ? 1 : 0;
-    const int rem = s - quad * PLANE;
-    const int hr = rem / ROWP, xp = rem - hr * ROWP;
-    const int hx = 4 * (xp % 9) + xp / 9;
-    const int iy = oy0 - 1 + hr, ix = ox0 - 1 + hx;
-    const bool ok = s < HALO_SLOTS && xp < 36 && hx < TW + 2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    hvoff[k] = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + 4 * quad) * 4) : OOB;
-  }
+    for (int k = 0; k < HALO_DMA_PER_WAVE; ++k) {
+      const int s = (wave + 8 * k) * 64 + lane;
+      const int quad = s >= PLANE ? 1 : 0;
+      const int rem = s - quad * PLANE;
+      const int hr = rem / ROWP, xp = rem - hr * ROWP;
+      const int hx = 4 * (xp % 9) + xp / 9;
+      const int iy = T.oy0 - 1 + hr, ix = T.ox0 - 1 + hx;
+      const bool ok = s < HALO_SLOTS && xp < 36 && hx < TW + 2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      hvoff[k] = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + 4 * quad) * 4) : OOB;
+    }
+  };
+  set_halo(cur);
   auto dma_halo = [&](int ch, int stage) {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(ch * (KC * 4));
 #pragma unroll
@@ -113,7 +138,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   constexpr unsigned RB = ROWP * 16;
 #define ODVAE_W4_D(r, c) lds_ld64f(rd + (r) * RB + ((((c) & 3) * 9 + ((c) >> 2)) * 16))
   auto transform = [&](unsigned hsrc, unsigned vdst) {
-    const unsigned rd = hsrc + t_rd, wr = vdst + t_wr;
+    unsigned rd = hsrc + t_rd, wr = vdst + t_wr;
+    asm volatile("" : "+v"(rd), "+v"(wr));      // opaque: the secondary base registers of the ds_read2 / ds_write pairs are re-derived per call, not kept
     if (role == 0) {
       f32x2 t1[6], t2[6];
 #pragma unroll
@@ -154,64 +180,102 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   };
 #undef ODVAE_W4_D
 
-  // ---- weight fragments: buffer loads with a scalar (xi, chunk) offset, as in the F(2x2) kernel ----
+  // ---- weight fragments: buffer loads with a scalar (xi, chunk) offset, as in the F(2x2) kernel -- but issued from inline asm, like
+  // the halo DMA: vmcnt retires in order, and hipcc, counting only the loads it knows, asks for `vmcnt(8)` in front of every xi, which
+  // with the three DMA instructions of the chunk in the queue means "the halo issued a moment ago must have landed" from xi 6 on
+  // (measured: 8.6 % of the kernel).  With every vector-memory instruction of the loop hidden from it the waits are written by hand:
+  // a fragment is awaited with exactly the loads younger than it left in flight.
   const int QT = p.CinP / 4;
   const int nchunks = p.CinP / KC;
-  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.upk), 0, 36 * p.CinP * p.CoutP * 4, 0x00020000);
+  const i32x4_t urs = rsrc_words(p.upk, (unsigned)(36 * p.CinP * p.CoutP) * 4u);
   const unsigned b_voff = (unsigned)((h * p.CoutP + n0 + ct * 32 + li) * 16);
   const int b_row = p.CoutP * 16;
-  auto load_b = [&](int ch, int j) {
+  auto load_b = [&](int ch, int j, f32x4& dst) {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((9 * g + j) * QT + 2 * ch) * b_row);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ursrc, b_voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(b_voff), "s"(urs), "s"(soff) : "memory");
   };
+#define ODVAE_W4_AWAIT(N, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(N) : "memory")
 
   f32x16 acc[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  float4 b[9];
+  // the last two chunks have no halo to fetch: their DMA slots run against an empty descriptor (nothing is read, zeros land in a
+  // halo stage nobody reads any more), so that the number of loads in flight is the same in every chunk
+  auto dma_halo_or_none = [&](int ch, int stage) {
+    const bool live = ch < nchunks;
+    i32x4_t r = xrs;
+    r.z = live ? xrs.z : 0;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(live ? ch * (KC * 4) : 0);
+#pragma unroll
+    for (int k = 0; k < HALO_DMA_PER_WAVE; ++k)
+      lds_dma16_s(r, (unsigned)__builtin_amdgcn_readfirstlane((int)(halo0 + stage * HALO_B + (wave + 8 * k) * 1024u)), hvoff[k], soff);
+  };
+
+  f32x4 b[9];
   dma_halo(0, 0);
 #pragma unroll
-  for (int j = 0; j < 9; ++j) b[j] = load_b(0, j);
-  if (nchunks > 1) { dma_halo(1, 1); wait_vm_but<9 + HALO_DMA_PER_WAVE>(); }
-  else wait_vm_but<9>();
+  for (int j = 0; j < 9; ++j) load_b(0, j, b[j]);
+  dma_halo_or_none(1, 1);
+  wait_vm_but<9 + HALO_DMA_PER_WAVE>();
   __syncthreads();
   transform(halo0, v0);
   wait_vm_but<0>();
   __syncthreads();
 
   // Loop body per xi: the A fragment of xi+1 is requested before the four MFMAs of xi, the weight fragment of xi is re-requested for
-  // the next chunk right behind them (unconditionally: past the last chunk it reloads the current one, which nobody reads).  The
+  // the next chunk right behind them.  The
   // two waves of a SIMD run their share of the input transform at different points of the chunk (after xi 2 / after xi 6), so one
   // of them always has MFMAs to issue while the other waits on LDS.
+  // Loads younger than fragment xi of this chunk when it is awaited: the fragments xi+1 .. 8 requested in the previous chunk, the
+  // three DMA instructions from the top of this one, the refills 0 .. xi-1: always 11.
+  // Persistent form: the next tile's first two halo chunks are requested before the output transform of this one and are awaited in the middle of it (counted: the
+  // stores of the passes since are the only younger vector-memory instructions), so a tile after the first starts with its first
+  // input transform instead of an HBM round trip.
   const unsigned a_off = (unsigned)(9 * g * 1024 + lane * 16);
   const int t_at = wave < 4 ? 2 : 6;
+  for (;;) {      // tiles of this block
+  const int s_nxt = s_cur + TL;
+  const bool has_next = p.persist && s_nxt < total_tiles;
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   for (int ch = 0; ch < nchunks; ++ch) {
     const unsigned Vc = v0 + (ch & 1) * V_B + a_off;
     const bool more = ch + 1 < nchunks;
-    const int chn = more ? ch + 1 : ch;
-    if (ch + 2 < nchunks) dma_halo(ch + 2, ch & 1);
+    if (!(ODVAE_W4_ABL & 16)) dma_halo_or_none(ch + 2, ch & 1);
     f32x4 a = lds_ld128f(Vc);
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       f32x4 an = a;
-      if (j < 8) an = lds_ld128f(Vc + (j + 1) * 1024);
+      if (j < 8 && !(ODVAE_W4_ABL & 8)) an = lds_ld128f(Vc + (j + 1) * 1024);
+      if (more) ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : 8 + HALO_DMA_PER_WAVE, b[j]);
+      else ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : 8 + HALO_DMA_PER_WAVE - j, b[j]);      // no refills in the last chunk
       acc[j] = mfma32(a.x, b[j].x, acc[j]);
       acc[j] = mfma32(a.y, b[j].y, acc[j]);
       acc[j] = mfma32(a.z, b[j].z, acc[j]);
       acc[j] = mfma32(a.w, b[j].w, acc[j]);
-      b[j] = load_b(chn, j);
+      if (!(ODVAE_W4_ABL & 4) && more) load_b(ch + 1, j, b[j]);
       a = an;
-      if ((j == 2 || j == 6) && j == t_at && more) transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
+      if (!(ODVAE_W4_ABL & 2) && (j == 2 || j == 6) && j == t_at && more)
+        transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
     }
-    if (ch + 2 < nchunks) wait_vm_but<9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
-    __syncthreads();
+    if (!(ODVAE_W4_ABL & 32)) wait_vm_but<(ODVAE_W4_ABL & 20) ? 0 : 9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
+    if (!(ODVAE_W4_ABL & 64)) __syncthreads();
+  }
+  const int n = cur.n, oy0 = cur.oy0, ox0 = cur.ox0;
+  if (has_next) {
+    cur = decode(s_nxt);
+    set_halo(cur);
+    dma_halo(0, 0);
+    dma_halo_or_none(1, 1);
   }
 
   // ---- output transform, one tile row (= accumulator registers 4 rq .. 4 rq + 3) at a time through X[ct][xi][e][lane] ----
+  // (its per-lane constants are derived from an opaque copy of the lane id: computed here, once per tile, instead of being hoisted
+  // out of the tile loop and kept -- spilled -- across the main loop)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int li_e = lane_e & 31, h_e = lane_e >> 5;
   const unsigned X0 = v0;
   const int img_bytes = p.H * p.W * p.Cout * 4;
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
@@ -219,33 +283,39 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, p.residual ? img_bytes : 0, 0x00020000);
   const bool relu = p.act != 0;
   const int ct2 = wave & 1, e2 = wave >> 1;        // the (co tile, register) this thread finishes in every pass
-  const int co = n0 + ct2 * 32 + li;
+  const int co = n0 + ct2 * 32 + li_e;
   const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
   const int cstep = p.Cout * 4, rstep = p.W * p.Cout * 4;
-  const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane) * 4);
-  const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane) * 4);
+  const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane_e) * 4);
+  const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane_e) * 4);
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) lds_st32f(x_wr + (j * 4 + e) * 256, acc[j][4 * rq + e]);
+      for (int e = 0; e < 4; ++e) if (!(ODVAE_W4_ABL & 256)) lds_st32f(x_wr + (j * 4 + e) * 256, acc[j][4 * rq + e]);
     // element (register 4 rq + e2, lane) is tile (row rq, column 4 h + e2): a 4x4 pixel block of one output channel
-    const int py = oy0 + 4 * rq, px = ox0 + 4 * (4 * h + e2);
+    const int py = oy0 + 4 * rq, px = ox0 + 4 * (4 * h_e + e2);
     const unsigned base = (py < p.H && px < p.W && co < p.Cout) ? (unsigned)(((py * p.W + px) * p.Cout + co) * 4) : OOB;
-    float seed[4][4];
+    float seed[4][4];      // bias (+ residual, requested before the exchange barrier)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        seed[a][c] = bv + __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, base, a * rstep + c * cstep, 0));
-    __syncthreads();
+      for (int c = 0; c < 4; ++c) seed[a][c] = bv;
+    if (p.residual) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          seed[a][c] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, base, a * rstep + c * cstep, 0));
+    }
+    if (!(ODVAE_W4_ABL & 512)) __syncthreads();
     float tt[6][4];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       float m[6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) m[j] = lds_ld32f(x_rd + (6 * i + j) * 1024);
+      for (int j = 0; j < 6; ++j) m[j] = (ODVAE_W4_ABL & 256) ? acc[(6 * i + j) % 9][4 * rq + (i & 3)] : lds_ld32f(x_rd + (6 * i + j) * 1024);
       const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
       tt[i][0] = m[0] + s1 + s2;
       tt[i][1] = d1 + 2.f * d2;
@@ -262,10 +332,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       yv[3] = d1 + 8.f * d2 + tt[5][c] + seed[3][c];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(yv[a], 0.f) : yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
+        if (!(ODVAE_W4_ABL & 128) || yv[a] == 12345.678f)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(yv[a], 0.f) : yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
     }
-    if (rq < 3) __syncthreads();     // X is rewritten by the next pass
+    // the next tile's halo: with a residual the 16 loads + 16 stores of pass 0 are younger than it, without one the 32 stores of passes 0, 1
+    if (has_next && rq == (p.residual ? 0 : 1)) wait_vm_but<32>();
+    if (rq < 3 && !(ODVAE_W4_ABL & 512)) __syncthreads();     // X is rewritten by the next pass
   }
+  if (!has_next) break;
+  s_cur = s_nxt;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) load_b(0, j, b[j]);      // (not kept across the output transform: the registers are needed there)
+  __syncthreads();         // X (over both V stages) has been read
+  transform(halo0, v0);
+  __syncthreads();
+  }      // tiles
 }
 
 // U[xi = 6a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles.  One thread per
@@ -334,7 +415,7 @@ size_t odvae_conv3x3_wino4_pack_floats(int c_reduce, int c_out) {
 }
 // shapes the F(4x4) kernel takes (forward: reduce over Cin; the data gradient swaps the roles, so both must qualify)
 int odvae_conv3x3_wino4_supported(int H, int W, int Cin, int Cout) {
-  return H % 4 == 0 && W % 4 == 0 && H >= TH && W >= TW && Cin % KC == 0 && Cout % KC == 0 && Cin >= 32 && Cout >= 32;
+  return H % 4 == 0 && W % 4 == 0 && H >= TH && W >= TW && Cin % KC == 0 && Cout % KC == 0 && Cin >= BN && Cout >= BN;
 }
 
 int odvae_conv3x3_pack_wino4_f32(const float* w, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream) {
@@ -380,7 +461,17 @@ int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const 
     odvae_set_error("conv3x3_wino4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     return ODVAE_ERR_HIP;
   }
-  hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)sp, p.CoutP / BN), dim3(512), LDS_B, static_cast<hipStream_t>(stream), p);
+  // persistent form: one block per CU; needs a grid that splits evenly over the output-channel blocks and >= 2 tiles per block
+  static const bool no_persist = getenv("ODVAE_WINO_PERSIST") != nullptr && atoi(getenv("ODVAE_WINO_PERSIST")) == 0;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int ny = p.CoutP / BN;
+  p.persist = (!no_persist && cus % (8 * ny) == 0 && sp >= 2 * (cus / ny)) ? 1 : 0;
+  if (p.persist) hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3(cus), dim3(512), LDS_B, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)sp, ny), dim3(512), LDS_B, static_cast<hipStream_t>(stream), p);
   ODVAE_LAUNCH_CHECK("conv3x3_wino4");
   return ODVAE_OK;
 }

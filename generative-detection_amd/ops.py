@@ -220,7 +220,7 @@ def _wino_ok(h, w, cin, cout):
 
 
 # F(4x4, 3x3) (conv3x3_wino4_f32.hip) where the shape allows: 36 products per 4x4 tile instead of 64.  ODVAE_CONV_WINOGRAD4=0/1.
-WINOGRAD4 = os.environ.get("ODVAE_CONV_WINOGRAD4", "0") == "1"
+WINOGRAD4 = os.environ.get("ODVAE_CONV_WINOGRAD4", "1") != "0"
 
 
 def _wino4_ok(h, w, cin, cout):

@@ -8,8 +8,8 @@ if os.environ.get("ODVAE_PROBE_LIB"):
 dev = "cuda:0"
 F = torch.nn.functional
 ops.WINOGRAD4 = True
-shapes = [(1, 32, 64, 16, 32), (2, 32, 64, 20, 36), (1, 40, 96, 16, 32), (2, 128, 128, 64, 48), (1, 64, 256, 24, 40), (3, 256, 128, 16, 32),
-          (1, 512, 512, 32, 32), (2, 128, 128, 128, 128), (2, 8 * 9, 8 * 5, 36, 68)]
+shapes = [(1, 64, 64, 16, 32), (2, 64, 64, 20, 36), (1, 72, 96, 16, 32), (2, 128, 128, 64, 48), (1, 64, 256, 24, 40), (3, 256, 128, 16, 32),
+          (1, 512, 512, 32, 32), (2, 128, 128, 128, 128), (2, 8 * 9, 8 * 11, 36, 68)]
 for (b, cin, cout, h, wd) in [] if os.environ.get("WINO_NOCHECK") else shapes:
     assert ops._wino4_ok(h, wd, cin, cout), (h, wd, cin, cout)
     x = torch.randn(b, h, wd, cin, device=dev).permute(0, 3, 1, 2).requires_grad_(True)
