@@ -96,7 +96,9 @@ __device__ __forceinline__ void lds_dma16(i32x4_t rsrc, unsigned lds_dst, unsign
 __device__ __forceinline__ void lds_dma16_s(i32x4_t rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  // (s_nop 2: with the two s_mov in front five wait states between a VALU write of `soff` / `rsrc` -- v_readlane of a spilled SGPR --
+  // and the vector-memory instruction that reads them; hipcc does not look into inline asm for that hazard)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
 #else
   (void)rsrc; (void)lds_dst; (void)voff; (void)soff;

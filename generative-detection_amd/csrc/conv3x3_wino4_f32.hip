@@ -192,7 +192,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   const int b_row = p.CoutP * 16;
   auto load_b = [&](int ch, int j, f32x4& dst) {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((9 * g + j) * QT + 2 * ch) * b_row);
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(b_voff), "s"(urs), "s"(soff) : "memory");
+    // (s_nop: the scalar offset may have been written by a VALU instruction -- v_readlane of a spilled SGPR -- which a vector-memory
+    // instruction may read only five wait states later; hipcc does not look into inline asm for that hazard)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(b_voff), "s"(urs), "s"(soff) : "memory");
   };
 #define ODVAE_W4_AWAIT(N, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(N) : "memory")
 

@@ -9,7 +9,8 @@ dev = "cuda:0"
 F = torch.nn.functional
 ops.WINOGRAD4 = True
 shapes = [(1, 64, 64, 16, 32), (2, 64, 64, 20, 36), (1, 72, 96, 16, 32), (2, 128, 128, 64, 48), (1, 64, 256, 24, 40), (3, 256, 128, 16, 32),
-          (1, 512, 512, 32, 32), (2, 128, 128, 128, 128), (2, 8 * 9, 8 * 11, 36, 68)]
+          (1, 512, 512, 32, 32), (2, 128, 128, 128, 128), (2, 8 * 9, 8 * 11, 36, 68),
+          (8, 128, 128, 128, 128), (2, 128, 128, 256, 512), (5, 64, 256, 112, 160), (3, 256, 512, 64, 96)]   # several tiles per block (persistent form)
 for (b, cin, cout, h, wd) in [] if os.environ.get("WINO_NOCHECK") else shapes:
     assert ops._wino4_ok(h, wd, cin, cout), (h, wd, cin, cout)
     x = torch.randn(b, h, wd, cin, device=dev).permute(0, 3, 1, 2).requires_grad_(True)
