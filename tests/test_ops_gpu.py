@@ -141,9 +141,18 @@ def test_conv3x3_direct_kernel_still_matches(hip_lib, monkeypatch, case):
     test_conv3x3_fwd_bwd(hip_lib, *case)
 
 
-def test_winograd_and_direct_kernels_agree(hip_lib, monkeypatch):
-    """Same f32 inputs through both kernels: forward and data gradient agree to a few 1e-6 of max|y| (summation order)."""
+# Winograd against the direct kernel, in max|difference| / max|y|.  F(2x2, 3x3) differs by summation order only; F(4x4, 3x3)
+# (interpolation points 0, +-1, +-2: transform coefficients up to 8 and 1/24) is an order of magnitude less exact in f32:
+# measured 0.5e-5 .. 2.4e-5 against an f64 convolution over Cin = 64 .. 512 (tools/wino4_time.py), bound here at 5e-5.
+WINO_TOL = {False: 1e-5, True: 5e-5}
+
+
+@pytest.mark.parametrize("f4", [False, True])
+def test_winograd_and_direct_kernels_agree(hip_lib, monkeypatch, f4):
+    """Same f32 inputs through both kernels: forward and data gradient agree to a few 1e-6 (F(2x2)) / 1e-5 (F(4x4)) of max|y|."""
     from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD4", f4)
+    assert bool(ops._wino4_ok(32, 48, 128, 128)) == f4
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 128, 32, 48, generator=g).to(dev())
     w = (torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(9 * 128)).to(dev())
@@ -156,16 +165,19 @@ def test_winograd_and_direct_kernels_agree(hip_lib, monkeypatch):
         y.backward(gy)
         outs.append((y.detach(), xd.grad))
     for a, b in zip(*outs):
-        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+        assert (a - b).abs().max().item() <= WINO_TOL[f4] * b.abs().max().item()
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(4, 128, 128, 128, 128), (5, 64, 128, 112, 160), (3, 128, 256, 64, 96), (2, 64, 512, 64, 128)])
-def test_winograd_persistent_form(hip_lib, monkeypatch, n, cin, cout, h, w):
+@pytest.mark.parametrize("f4", [False, True])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(4, 128, 128, 128, 128), (5, 64, 128, 112, 160), (3, 128, 256, 64, 96), (2, 64, 512, 64, 128),
+                                            (8, 128, 128, 128, 128), (3, 64, 128, 160, 320)])
+def test_winograd_persistent_form(hip_lib, monkeypatch, n, cin, cout, h, w, f4):
     """Layers with at least two tiles per block run the persistent form of the Winograd kernel (the chunk pipeline carries on
     across the tile boundary; conv3x3_wino_f32.hip): 512 / 700 / 288 / 256 tiles over 256 / 256 / 128 / 64 blocks per output-channel
     block, i.e. even and uneven tile counts per block and one, two and four co blocks.  Forward (bias + residual) against torch on
     the host, forward and data gradient against the direct kernel, and a bit-identical repeat."""
     from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD4", f4)     # F(4x4): 16 x 32-pixel tiles, 64-channel blocks -- the last two shapes give it 256 / 300 tiles over 128 blocks
     g = torch.Generator().manual_seed(n * 7 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
@@ -182,7 +194,7 @@ def test_winograd_persistent_form(hip_lib, monkeypatch, n, cin, cout, h, w):
         outs.append((y.detach(), xd.grad))
     close(outs[0][0], ref, FWD_TOL, "persistent winograd fwd vs torch")
     for a, d in zip(*outs):
-        assert (a - d).abs().max().item() <= 1e-5 * d.abs().max().item()
+        assert (a - d).abs().max().item() <= WINO_TOL[f4] * d.abs().max().item()
     monkeypatch.setattr(ops, "WINOGRAD", True)
     with torch.no_grad():
         again = ops.conv3x3(x.to(dev()), wt.to(dev()), b.to(dev()), res.to(dev()))

@@ -26,7 +26,7 @@ for (b, cin, cout, h, wd) in [] if os.environ.get("WINO_NOCHECK") else shapes:
     err = (y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
     derr = (dx.double().cpu() - dref).abs().max().item() / dref.abs().max().item()
     with torch.no_grad():
-        yr = ops.conv3x3(x, w, None, relu=True)
+        yr = ops.conv3x3(x, w, None, relu=True)      # (fused ReLU: the F(2x2) kernel, see ops._Conv3x3)
         rr = F.relu(F.conv2d(xc, wc, None, padding=1))
     rerr = (yr.double().cpu() - rr).abs().max().item() / rr.abs().max().item()
     ok = max(err, derr, rerr) < 3e-5
