@@ -90,7 +90,7 @@ class _KernelEvents:
             return
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        self.rec.setdefault(name, []).append((flops, ev0, ev1, nbytes))
+        self.rec.setdefault(name, []).append((flops, ev0, ev1, nbytes, flops if issued is None else issued))
 
     def summary(self, name):
         torch.cuda.synchronize()
@@ -100,8 +100,10 @@ class _KernelEvents:
         total_ms = sum(it[1].elapsed_time(it[2]) for it in items)
         flops = sum(it[0] for it in items)
         nbytes = sum(it[3] for it in items)
+        issued = sum(it[4] for it in items)
         return {"launches": len(items), "total_ms": total_ms, "avg_ms": total_ms / len(items),
                 "gflop_per_launch": flops / len(items) / 1e9, "tflops": flops / total_ms / 1e9,
+                "issued_gflop_per_launch": issued / len(items) / 1e9, "issued_tflops": issued / total_ms / 1e9,
                 "bytes_per_launch": nbytes / len(items), "tbytes_per_s": nbytes / total_ms / 1e9}
 
 
@@ -236,7 +238,7 @@ def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False):
     _lib.check(fn(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
                   y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino4" if f4 else "conv3x3_wino")
     # issued multiply-adds per output pixel and (ci, co): F(2x2,3x3) 16 per 2x2 tile = 4, F(4x4,3x3) 36 per 4x4 tile = 2.25
-    KERNEL_EVENTS.end("conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
+    KERNEL_EVENTS.end("conv3x3_wino4" if f4 else "conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
                       4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
                       issued=2.0 * (2.25 if f4 else 4.0) * cin * cout * n * h * w)
     return y

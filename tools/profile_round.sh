@@ -10,7 +10,7 @@ tools/profile_step.sh ${tag}_f32 "B=32, 256x256, fp32, rec+KL only" --steps 3 --
 tools/profile_step.sh ${tag}_bf16_256 "B=32, 256x256, bf16 mixed precision, rec+KL only" --bf16 --steps 3 --warmup 1
 tools/profile_step.sh ${tag}_bf16_512 "B=32, 512x512, z=32x32x16, bf16 mixed precision, activation-checkpointed Decoder" --bf16 --res 512 --batch 32 --ckpt-decoder --steps 2 --warmup 1
 cd /tmp && export TMPDIR=/tmp
-for cfg in "f32:conv3x3_wino8_kernel:" "bf16:conv_bf16_kernel:--bf16"; do
+for cfg in "f32:conv3x3_wino4_kernel:" "bf16:conv_bf16_kernel:--bf16"; do
   name=${cfg%%:*}; rest=${cfg#*:}; kern=${rest%%:*}; flag=${rest#*:}
   for ctr in FETCH_SIZE WRITE_SIZE; do
     out=/tmp/pmc_${name}_$ctr; rm -rf $out
