@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   __syncthreads();
 
   // Loop body per xi: the A fragment of xi+1 is requested before the four MFMAs of xi, the weight fragment of xi is re-requested for
-  // the next chunk right behind them.  The
+  // the next chunk right behind them (past the last chunk: for chunk 0 of the next tile).  The
   // two waves of a SIMD run their share of the input transform at different points of the chunk (after xi 2 / after xi 6), so one
   // of them always has MFMAs to issue while the other waits on LDS.
   // Loads younger than fragment xi of this chunk when it is awaited: the fragments xi+1 .. 8 requested in the previous chunk, the
@@ -244,19 +244,19 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const unsigned Vc = v0 + (ch & 1) * V_B + a_off;
     const bool more = ch + 1 < nchunks;
+    const int chn = more ? ch + 1 : 0;      // past the last chunk: chunk 0 again, the next tile's first fragments (same output channels)
     if (!(ODVAE_W4_ABL & 16)) dma_halo_or_none(ch + 2, ch & 1);
     f32x4 a = lds_ld128f(Vc);
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
       f32x4 an = a;
       if (j < 8 && !(ODVAE_W4_ABL & 8)) an = lds_ld128f(Vc + (j + 1) * 1024);
-      if (more) ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : 8 + HALO_DMA_PER_WAVE, b[j]);
-      else ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : 8 + HALO_DMA_PER_WAVE - j, b[j]);      // no refills in the last chunk
+      ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : 8 + HALO_DMA_PER_WAVE, b[j]);
       acc[j] = mfma32(a.x, b[j].x, acc[j]);
       acc[j] = mfma32(a.y, b[j].y, acc[j]);
       acc[j] = mfma32(a.z, b[j].z, acc[j]);
       acc[j] = mfma32(a.w, b[j].w, acc[j]);
-      if (!(ODVAE_W4_ABL & 4) && more) load_b(ch + 1, j, b[j]);
+      if (!(ODVAE_W4_ABL & 4)) load_b(chn, j, b[j]);
       a = an;
       if (!(ODVAE_W4_ABL & 2) && (j == 2 || j == 6) && j == t_at && more)
         transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
     if (!(ODVAE_W4_ABL & 32)) wait_vm_but<(ODVAE_W4_ABL & 20) ? 0 : 9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
     if (!(ODVAE_W4_ABL & 64)) __syncthreads();
   }
+  wait_vm_but<0>();      // the last refills have landed: their registers stay live across the output transform
   const int n = cur.n, oy0 = cur.oy0, ox0 = cur.ox0;
   if (has_next) {
     cur = decode(s_nxt);
@@ -343,8 +344,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   }
   if (!has_next) break;
   s_cur = s_nxt;
-#pragma unroll
-  for (int j = 0; j < 9; ++j) load_b(0, j, b[j]);      // (not kept across the output transform: the registers are needed there)
   __syncthreads();         // X (over both V stages) has been read
   transform(halo0, v0);
   __syncthreads();
