@@ -58,7 +58,7 @@ __device__ __forceinline__ float lds_ld32f(unsigned a) { return *(const __attrib
 __device__ __forceinline__ void lds_st32f(unsigned a, float v) { *(__attribute__((address_space(3))) float*)(uintptr_t)a = v; }
 // -DODVAE_W4_ABL=<bits>: timing-only ablation builds (results are wrong): 1 no output transform, 2 no input transform in the loop,
 // 4 no weight refills, 8 no A-fragment reads, 16 no halo DMA in the loop, 32 no wait for the DMA at the end of a chunk, 64 no barrier,
-// 128 epilogue without the stores, 256 without the LDS exchange, 512 without its barriers
+// 128 epilogue without the stores, 256 without the LDS exchange, 512 without its barriers, 1024 every other weight refill only
 #ifndef ODVAE_W4_ABL
 #define ODVAE_W4_ABL 0
 #endif
@@ -251,17 +251,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
     for (int j = 0; j < 9; ++j) {
       f32x4 an = a;
       if (j < 8 && !(ODVAE_W4_ABL & 8)) an = lds_ld128f(Vc + (j + 1) * 1024);
-      ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : 8 + HALO_DMA_PER_WAVE, b[j]);
+      ODVAE_W4_AWAIT((ODVAE_W4_ABL & 20) ? 0 : (ODVAE_W4_ABL & 1024) ? 4 + HALO_DMA_PER_WAVE : 8 + HALO_DMA_PER_WAVE, b[j]);
       acc[j] = mfma32(a.x, b[j].x, acc[j]);
       acc[j] = mfma32(a.y, b[j].y, acc[j]);
       acc[j] = mfma32(a.z, b[j].z, acc[j]);
       acc[j] = mfma32(a.w, b[j].w, acc[j]);
-      if (!(ODVAE_W4_ABL & 4)) load_b(chn, j, b[j]);
+      if (!(ODVAE_W4_ABL & 4) && (!(ODVAE_W4_ABL & 1024) || (j & 1) == 0)) load_b(chn, j, b[j]);
       a = an;
       if (!(ODVAE_W4_ABL & 2) && (j == 2 || j == 6) && j == t_at && more)
         transform(halo0 + ((ch + 1) & 1) * HALO_B, v0 + ((ch + 1) & 1) * V_B);
     }
-    if (!(ODVAE_W4_ABL & 32)) wait_vm_but<(ODVAE_W4_ABL & 20) ? 0 : 9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
+    if (!(ODVAE_W4_ABL & 32)) wait_vm_but<(ODVAE_W4_ABL & 20) ? 0 : (ODVAE_W4_ABL & 1024) ? 5 : 9>();      // this wave's halo pieces of chunk ch+2 (older than the nine refills) have landed
     if (!(ODVAE_W4_ABL & 64)) __syncthreads();
   }
   wait_vm_but<0>();      // the last refills have landed: their registers stay live across the output transform
