@@ -201,6 +201,49 @@ def test_winograd_persistent_form(hip_lib, monkeypatch, n, cin, cout, h, w, f4):
     assert torch.equal(again, outs[0][0])
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,res,bias", [(1, 64, 64, 16, 32, True, True), (2, 72, 88, 20, 36, False, True), (1, 512, 512, 32, 32, True, False),
+                                                     (2, 64, 192, 36, 68, False, False)])
+def test_winograd4_through_the_c_abi(hip_lib, n, cin, cout, h, w, res, bias):
+    """odvae_conv3x3_pack_wino4_f32 + odvae_conv3x3_wino4_f32 called directly (minimum tile, partial blocks in both directions, channel counts
+    that are no multiple of the 64-channel block, 64 chunks; with / without bias and residual) against an f64 convolution on the host, forward
+    pack and data-gradient pack; then the contract: what `supported` names, and the error returns for shapes the kernel cannot take."""
+    from odvae_amd import lib as _lib, ops
+    L = hip_lib
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, h, w, cin, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g) if bias else None
+    r = torch.randn(n, h, w, cout, generator=g) if res else None
+    gy = torch.randn(n, h, w, cout, generator=g)
+    xd, wd, gyd = x.to(dev()), wt.to(dev()), gy.to(dev())
+    fwd = torch.empty(L.odvae_conv3x3_wino4_pack_floats(cin, cout), device=dev())
+    dgr = torch.empty(L.odvae_conv3x3_wino4_pack_floats(cout, cin), device=dev())
+    _lib.check(L.odvae_conv3x3_pack_wino4_f32(wd.data_ptr(), cout, cin, fwd.data_ptr(), dgr.data_ptr(), _lib.stream_ptr()), "pack_wino4")
+    y = torch.empty(n, h, w, cout, device=dev())
+    bd, rd = (b.to(dev()) if bias else None), (r.to(dev()) if res else None)
+    _lib.check(L.odvae_conv3x3_wino4_f32(xd.data_ptr(), n, h, w, cin, fwd.data_ptr(), cout, _lib.ptr(bd), _lib.ptr(rd), y.data_ptr(), 0,
+                                         _lib.stream_ptr()), "wino4 fwd")
+    dx = torch.empty(n, h, w, cin, device=dev())
+    _lib.check(L.odvae_conv3x3_wino4_f32(gyd.data_ptr(), n, h, w, cout, dgr.data_ptr(), cin, None, None, dx.data_ptr(), 0, _lib.stream_ptr()), "wino4 dgrad")
+    x64 = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    ref = F.conv2d(x64, wt.double(), b.double() if bias else None, padding=1)
+    dref, = torch.autograd.grad(ref, x64, gy.permute(0, 3, 1, 2).double())
+    if res:
+        ref = ref + r.permute(0, 3, 1, 2).double()
+    for got, want, what in ((y, ref, "forward"), (dx, dref, "data gradient")):
+        err = (got.cpu().permute(0, 3, 1, 2).double() - want.detach()).abs().max().item()
+        assert err <= WINO_TOL[True] * want.abs().max().item(), "%s: %.3e of max|y|" % (what, err / want.abs().max().item())
+    assert L.odvae_conv3x3_wino4_supported(h, w, cin, cout) == 1
+    assert L.odvae_conv3x3_wino4_supported(h + 2, w, cin, cout) == 0          # H, W in multiples of 4
+    assert L.odvae_conv3x3_wino4_supported(h, 16, cin, cout) == 0             # at least one 16 x 32 block
+    assert L.odvae_conv3x3_wino4_supported(h, w, cin + 4, cout) == 0          # channels in chunks of 8
+    assert L.odvae_conv3x3_wino4_supported(h, w, 32, cout) == 0               # thin layers stay on F(2x2)
+    assert L.odvae_conv3x3_wino4_f32(xd.data_ptr(), n, h + 2, w, cin, fwd.data_ptr(), cout, None, None, y.data_ptr(), 0, _lib.stream_ptr()) != 0
+    assert b"multiples of 4" in L.odvae_last_error()
+    assert L.odvae_conv3x3_wino4_f32(xd.data_ptr(), n, h, w, cin + 4, fwd.data_ptr(), cout, None, None, y.data_ptr(), 0, _lib.stream_ptr()) != 0
+    assert L.odvae_conv3x3_wino4_f32(None, n, h, w, cin, fwd.data_ptr(), cout, None, None, y.data_ptr(), 0, _lib.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 128, 16, 16), (1, 128, 256, 8, 12), (3, 256, 128, 6, 10),
                                             (2, 128, 128, 2, 2), (1, 384, 128, 4, 34)])
 def test_winograd_domain_weight_gradient(hip_lib, n, cin, cout, h, w):
