@@ -284,7 +284,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, p.residual ? img_bytes : 0, 0x00020000);
-  const bool relu = p.act != 0;
   const int ct2 = wave & 1, e2 = wave >> 1;        // the (co tile, register) this thread finishes in every pass
   const int co = n0 + ct2 * 32 + li_e;
   const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
         if (!(ODVAE_W4_ABL & 128) || yv[a] == 12345.678f)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(yv[a], 0.f) : yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
     }
     // the next tile's halo: with a residual the 16 loads + 16 stores of pass 0 are younger than it, without one the 32 stores of passes 0, 1
     if (has_next && rq == (p.residual ? 0 : 1)) wait_vm_but<32>();
@@ -438,11 +437,13 @@ int odvae_conv3x3_pack_wino4_f32(const float* w, int Cout, int Cin, float* fwd_p
   return ODVAE_OK;
 }
 
-// y = act(conv3x3_stride1_pad1(x) (+bias) (+residual)); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino4_f32.
+// y = conv3x3_stride1_pad1(x) (+bias) (+residual); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino4_f32; act must be 0
+// (a fused ReLU is not offered: ops.py keeps the ReLU convs of the VGG stack on F(2x2) for accuracy, see there).
 int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
                             const float* bias, const float* residual, float* y, int act, void* stream) {
   ODVAE_CHECK_ARG(x && upk && y, "conv3x3_wino4: null operand");
   ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino4: empty shape");
+  ODVAE_CHECK_ARG(act == 0, "conv3x3_wino4: no fused activation (act=%d); ReLU convs stay on odvae_conv3x3_wino_f32", act);
   ODVAE_CHECK_ARG(H % 4 == 0 && W % 4 == 0 && Cin % KC == 0, "conv3x3_wino4: needs H, W in multiples of 4 and Cin %% 8 == 0 (H=%d W=%d Cin=%d)", H, W, Cin);
   ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)upk & 15) == 0, "conv3x3_wino4: x/upk must be 16-byte aligned");
   ODVAE_CHECK_ARG((int64_t)H * W * Cin * 4 < 0x7FFFFFF0ll && ((int64_t)(H + 3) * W + 3) * Cout * 4 < 0x7FFFFFF0ll,

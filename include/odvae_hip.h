@@ -95,7 +95,7 @@ size_t odvae_conv3x3_wino4_pack_floats(int c_reduce, int c_out);
 int odvae_conv3x3_wino4_supported(int H, int W, int Cin, int Cout);
 int odvae_conv3x3_pack_wino4_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
 int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
-                            const float* bias, const float* residual, float* y, int act /* 0 none, 1 ReLU */, void* stream);
+                            const float* bias, const float* residual, float* y, int act /* must be 0: no fused activation */, void* stream);
 
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
  * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)

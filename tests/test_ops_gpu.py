@@ -242,6 +242,7 @@ def test_winograd4_through_the_c_abi(hip_lib, n, cin, cout, h, w, res, bias):
     assert b"multiples of 4" in L.odvae_last_error()
     assert L.odvae_conv3x3_wino4_f32(xd.data_ptr(), n, h, w, cin + 4, fwd.data_ptr(), cout, None, None, y.data_ptr(), 0, _lib.stream_ptr()) != 0
     assert L.odvae_conv3x3_wino4_f32(None, n, h, w, cin, fwd.data_ptr(), cout, None, None, y.data_ptr(), 0, _lib.stream_ptr()) != 0
+    assert L.odvae_conv3x3_wino4_f32(xd.data_ptr(), n, h, w, cin, fwd.data_ptr(), cout, None, None, y.data_ptr(), 1, _lib.stream_ptr()) != 0   # no fused ReLU
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 128, 16, 16), (1, 128, 256, 8, 12), (3, 256, 128, 6, 10),
