@@ -179,6 +179,44 @@ def test_three_step_loss_curve_matches_oracle(hip_lib, ch, height, latent_hw):
             assert diff <= 2.2 * lr * steps + 5e-3 * ref_sd[k].abs().max().item(), (k, diff)
 
 
+def test_eight_step_curve_f4x4_vs_f2x2_winograd(hip_lib, monkeypatch):
+    """The benchmark's own network (ch = 128) at 128 x 128, B = 4, eight optimizer steps, once with the stride-1 convs on the
+    Winograd F(4x4,3x3) kernel (default) and once on F(2x2,3x3) (ODVAE_CONV_WINOGRAD4=0; ten times closer to the direct form per
+    layer): same weights, batches and noise.  The loss curves agree to 2e-5 per step (measured 7e-7), the logged reconstruction / KL terms of
+    the last step to 1e-3, the weights after eight Adam steps to 2.2 lr per step (a gradient that is zero up to rounding may
+    move a weight either way) + 2e-3 of the tensor's largest entry."""
+    from odvae_amd import ops, synthetic
+    from odvae_amd.config import instantiate_from_config
+    from odvae_amd.trainer import Trainer
+    runs = {}
+    for f4 in (True, False):
+        monkeypatch.setattr(ops, "WINOGRAD4", f4)
+        torch.manual_seed(23)
+        mcfg, cfg = synthetic.model_config(YAML, latent_hw=8)
+        model = instantiate_from_config(mcfg)
+        model.learning_rate = 12 * cfg.model.base_learning_rate
+        model = model.to("cuda:0").train()
+        trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,))
+        curve = []
+        for step in range(8):
+            batch = synthetic.make_batch(4, 128, seed=300 + step)
+            model.injected_noise = synthetic.make_noise(4, 8, dropout_p=0.7, seed=400 + step)
+            curve.append(trainer.training_batch(batch, step)[0].item())
+        logs = {k: float(model.logged_metrics["train/" + k]) for k in ("rec_loss", "nll_loss", "kl_loss_obj")}
+        runs[f4] = (curve, logs, {k: v.detach().clone() for k, v in model.state_dict().items() if v.dtype == torch.float32}, model.learning_rate)
+        assert ops._wino4_ok(128, 128, 128, 128) == f4
+    (c4, l4, w4, lr), (c2, l2, w2, _) = runs[True], runs[False]
+    print("F(4x4) vs F(2x2) curve: max relative difference %.2e over %s" % (max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(c4, c2)), c2))
+    for a, b in zip(c4, c2):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (c4, c2)      # measured 7e-7
+    for k in l4:
+        assert abs(l4[k] - l2[k]) <= 1e-3 * max(1.0, abs(l2[k])), (k, l4[k], l2[k])
+    for k in w4:
+        if k.startswith(("encoder", "decoder", "quant", "post_quant")):
+            diff = (w4[k] - w2[k]).abs().max().item()
+            assert diff <= 2.2 * lr * 8 + 2e-3 * w2[k].abs().max().item(), (k, diff)
+
+
 def test_config1_golden_curve_at_full_width(hip_lib):
     """BASELINE.json configs[0] (yaml at full width, 64x64, B=2, 10 steps) on the HIP path against the committed fixture
     tests/golden/oracle_config1.npz: same initial weights (the generator's seeded oracle), same batches and noise."""
