@@ -16,8 +16,9 @@
 // consecutive rows, conflict-free).  Both reads use the same k order inside a group of 8:
 // step j of lane half h is k = 8g + 4h + j, so A and B always agree.
 // Split-K (grid.y) covers the long-K/small-MN products (wgrad: K = B*H*W).
-#include "common.h"
+#include "bf16_common.h"   // LDS in 32-bit addresses, LDS-DMA by inline asm
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -25,6 +26,15 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_KC = BK + 4;    // [row][k] tile row stride (floats)
 constexpr int LDS_RC = BM + 4;    // [k][row] tile row stride (floats)
 constexpr int TILE_FLOATS = BM * LDS_KC;  // 4608 >= BK*LDS_RC = 4224
+// LDS-DMA form (default): operand tiles go HBM/L2 -> LDS directly (`buffer_load ... lds`: no registers, no ds_write), unpadded,
+// two stages of {A, B} = 4 x 16 KB.  A k-contiguous tile [128 rows][8 slots of 16 B] is XOR-swizzled -- LDS slot (row, q') holds
+// k quad q = q' ^ ((row >> 1) & 7), chosen by the per-lane GLOBAL address, the LDS side of the DMA being linear in the lane -- so the
+// 16 rows of a ds_read_b128 phase land on 16 different bank groups (even rows on banks 0-31, odd rows on 32-63, eight slots each).
+// A row-contiguous tile [32 k][128 rows] is read as b32 by 32 consecutive rows: conflict-free as it is.
+constexpr unsigned DMA_TILE_B = BM * BK * 4;        // 16 384
+constexpr unsigned DMA_STAGE_B = 2 * DMA_TILE_B;    // A then B
+constexpr unsigned DMA_LDS_B = 2 * DMA_STAGE_B;     // 65 536
+__device__ __forceinline__ float lds_ld32(unsigned a) { return *(const __attribute__((address_space(3))) float*)(uintptr_t)a; }
 
 struct GemmParams {
   const float* A; const float* B; float* C;
@@ -77,6 +87,50 @@ struct TileFetch {
       }
     }
   }
+  // ---- LDS-DMA form ----
+  i32x4_t words;           // the same descriptor as raw dwords (inline asm operand)
+  __device__ __forceinline__ void init_dma(const float* G, int ld, int row0, int nrows, int kbeg, int kend) {
+    const int tid = threadIdx.x;
+    const unsigned OOB = 0x7FFFFFF0u;
+    kvalid = kend - kbeg;
+    if (KC) {
+      const int rows = min(BM, nrows - row0);
+      const int64_t bytes = ((int64_t)(rows - 1) * ld + kvalid) * 4;
+      words = rsrc_words(G + (int64_t)row0 * ld + kbeg, (unsigned)(bytes < 0x7FFFFFF0ll ? bytes : 0x7FFFFFF0ll));
+      step_bytes = BK * 4u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        const int row = f >> 3, q = (f & 7) ^ ((row >> 1) & 7);
+        voff[i] = (unsigned)((row * ld + 4 * q) * 4);
+      }
+    } else {
+      const int64_t bytes = ((int64_t)(kvalid - 1) * ld + (nrows - row0)) * 4;
+      words = rsrc_words(G + (int64_t)kbeg * ld + row0, (unsigned)(bytes < 0x7FFFFFF0ll ? bytes : 0x7FFFFFF0ll));
+      step_bytes = (unsigned)(BK * ld) * 4u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        voff[i] = (row0 + 4 * (f & 31) < nrows) ? (unsigned)(((f >> 5) * ld + 4 * (f & 31)) * 4) : OOB;
+      }
+    }
+  }
+  // tile of step `step` -> LDS at byte address `dst` (this operand's tile of the stage); slot f = tid + 256 i lands at dst + 16 f
+  __device__ __forceinline__ void dma(int step, unsigned dst) const {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(step) * step_bytes;
+    const bool tail = KC && (step + 1) * BK > kvalid;
+    const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (threadIdx.x >> 6) * 1024u));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned vo = voff[i];
+      if (tail) {
+        const int f = threadIdx.x + 256 * i;
+        const int q = (f & 7) ^ (((f >> 3) >> 1) & 7);
+        if (step * BK + 4 * q >= kvalid) vo = 0x7FFFFFF0u;
+      }
+      lds_dma16_s(words, (unsigned)__builtin_amdgcn_readfirstlane((int)(wbase + 4096u * i)), vo, soff);
+    }
+  }
   // tile of step `step` (k = kbeg + step * BK ...)
   __device__ __forceinline__ void load(int step, float4 (&r)[4]) const {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(step) * step_bytes;
@@ -117,6 +171,16 @@ __device__ __forceinline__ void read_frag(const float* S, int row, int g, int h,
   }
 }
 
+template <bool A_KC, bool B_KC, bool SMB, bool DMA>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem);
+
+// LDS-DMA form: 64 KB of dynamic LDS, two blocks per CU
+template <bool A_KC, bool B_KC, bool SMB = false>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  gemm_body<A_KC, B_KC, SMB, true>(p, dsm);
+}
+
 template <bool A_KC, bool B_KC, bool SMB = false, bool OCC3 = (A_KC && B_KC && !SMB)>
 // OCC3: three blocks per CU (150 registers, the accumulators in VGPRs).  The form with both operands k-contiguous (QK^T-shaped
 // and 1x1-forward products) gains 4-6 % from the third block covering prologue / store bursts, the unsplit batched TN products
@@ -124,6 +188,11 @@ template <bool A_KC, bool B_KC, bool SMB = false, bool OCC3 = (A_KC && B_KC && !
 // (tools/gemm_probe.py).
 __global__ __launch_bounds__(256, OCC3 ? 3 : 1) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+  gemm_body<A_KC, B_KC, SMB, false>(p, smem);
+}
+
+template <bool A_KC, bool B_KC, bool SMB, bool DMA>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
   float* As = smem;
   float* Bs = smem + TILE_FLOATS;
 
@@ -193,6 +262,70 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : 1) void gemm_f32_kernel(GemmParams 
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
 
+  if constexpr (DMA) {
+    // One barrier per step: the tiles of step s+1 are requested (LDS-DMA, inline asm: invisible to hipcc's vmcnt bookkeeping, awaited by
+    // hand) into the other stage at the top of step s and have its 64 MFMAs per wave to land.  Fragment addresses: one VGPR per
+    // (operand, k group) computed once; stage and tile are immediates (the loop body is written out for both stages).
+    const unsigned lds0 = lds_addr_of(smem);
+    TileFetch<A_KC> fa;
+    TileFetch<B_KC> fb;
+    const int nsteps = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nsteps > 0) {
+      fa.init_dma(A, p.lda, m0, p.M, kbeg, kend);
+      fb.init_dma(B, p.ldb, n0, p.N, kbeg, kend);
+      fa.dma(0, lds0);
+      fb.dma(0, lds0 + DMA_TILE_B);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned hs = (unsigned)(h ^ ((li >> 1) & 7));
+    unsigned adrA[4], adrB[4];      // KC: row base + swizzled slot of k group g; row-contiguous: one base (adr[0])
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      adrA[g] = A_KC ? lds0 + (unsigned)((wm * 64 + li) * 128) + ((hs ^ (2u * g)) << 4) : lds0 + (unsigned)((4 * h * 128 + wm * 64 + li) * 4);
+      adrB[g] = B_KC ? lds0 + DMA_TILE_B + (unsigned)((wn * 64 + li) * 128) + ((hs ^ (2u * g)) << 4)
+                     : lds0 + DMA_TILE_B + (unsigned)((4 * h * 128 + wn * 64 + li) * 4);
+    }
+    auto frag = [&](auto kc, const unsigned (&adr)[4], unsigned stage_b, int g, int t, float (&v)[4]) {
+      if constexpr (decltype(kc)::value) {
+        const f32x4 x = lds_ld128f(adr[g] + stage_b + (unsigned)(t * 32 * 128));
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = lds_ld32(adr[0] + stage_b + (unsigned)(((g * 8 + j) * 128 + t * 32) * 4));
+      }
+    };
+    auto body = [&](auto stage, int step) {
+      constexpr unsigned ST = decltype(stage)::value * DMA_STAGE_B;
+      if (step + 1 < nsteps) {
+        fa.dma(step + 1, lds0 + (DMA_STAGE_B - ST));
+        fb.dma(step + 1, lds0 + (DMA_STAGE_B - ST) + DMA_TILE_B);
+      }
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          frag(std::integral_constant<bool, A_KC>{}, adrA, ST, g, t, a[t]);
+          frag(std::integral_constant<bool, B_KC>{}, adrB, ST, g, t, b[t]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(a[mt][j], b[nt][j], acc[mt][nt]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+      body(std::integral_constant<unsigned, 0>{}, step);
+      body(std::integral_constant<unsigned, 1>{}, step + 1);
+    }
+    if (step < nsteps) body(std::integral_constant<unsigned, 0>{}, step);
+  } else {
   float4 ra[4], rb[4];
   TileFetch<A_KC> fa;
   TileFetch<B_KC> fb;
@@ -235,6 +368,7 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : 1) void gemm_f32_kernel(GemmParams 
       __syncthreads();
     }
   }
+  }      // register-staged form
 
   // epilogue: lane owns column (n0 + wn*64 + nt*32 + li); rows come from the register index.  Stores only.
   const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(Cb + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
@@ -297,6 +431,23 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
   }
 }
 
+// ODVAE_GEMM_DMA: unset = per shape (see odvae_gemm_f32), 1 = LDS-DMA form everywhere, 0 = register-staged form everywhere
+int g_dma_mode = -2;      // -2: environment not read yet
+int dma_mode() {
+  if (g_dma_mode == -2) g_dma_mode = getenv("ODVAE_GEMM_DMA") == nullptr ? -1 : (atoi(getenv("ODVAE_GEMM_DMA")) != 0 ? 1 : 0);
+  return g_dma_mode;
+}
+template <typename K>
+int launch_dma(K kern, dim3 grid, hipStream_t st, const GemmParams& p) {
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_B);
+  if (e != hipSuccess) {
+    odvae_set_error("gemm_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return ODVAE_ERR_HIP;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), DMA_LDS_B, st, p);
+  return ODVAE_OK;
+}
+
 int choose_splits(int M, int N, int K, int batch) {
   const int64_t tiles = (int64_t)ceil_div(M, BM) * ceil_div(N, BN) * batch;
   static const int target = getenv("ODVAE_GEMM_SPLIT_BLOCKS") ? atoi(getenv("ODVAE_GEMM_SPLIT_BLOCKS")) : 512;   // two blocks per CU; 1024 / 256 measured 8-12 % slower
@@ -311,6 +462,15 @@ int choose_splits(int M, int N, int K, int batch) {
 }  // namespace
 
 extern "C" {
+
+// Operand staging of odvae_gemm_f32 / odvae_gemm_softmax_bwd_f32: -1 per shape (default), 0 through registers (global -> VGPR -> ds_write,
+// one LDS stage, up to three blocks per CU), 1 by LDS-DMA (two stages, one barrier per step).  ODVAE_GEMM_DMA presets it.  Returns the
+// previous setting.  Results are identical (same products, same summation order).
+int odvae_gemm_select_staging(int mode) {
+  const int prev = dma_mode();
+  g_dma_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
+}
 
 // bytes of split-K scratch odvae_gemm_f32 needs for this shape (0 when it runs unsplit)
 size_t odvae_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
@@ -360,7 +520,21 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   ODVAE_CHECK_ARG((a_kc ? (int64_t)BM * lda : (int64_t)p.k_per_split * lda) * 4 < 0x7FFFFFF0ll &&
                   (b_kc ? (int64_t)BN * ldb : (int64_t)p.k_per_split * ldb) * 4 < 0x7FFFFFF0ll,
                   "gemm_f32: one block's operand window exceeds 2 GiB (lda=%d ldb=%d K per split=%d)", lda, ldb, p.k_per_split);
-  if (a_kc && b_kc)        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, p);
+  // Which form: measured on the step's shapes (tools/gemm_probe.py, TFLOP/s, LDS-DMA vs register-staged): TN (both operands
+  // row-contiguous: dV = P^T dO, dK = dS^T Q, the 1x1 weight gradients) 140.6 vs 132.3 and 127.2 vs 120.7; NN 132.6 vs 133.5; NT (both
+  // k-contiguous, K = 256: QK^T, dO V^T, 1x1 forward) 122.2 vs 129.3 -- eight steps per block there, and the 64 KB of the two DMA stages
+  // cost the third block per CU that covers prologue and store bursts.  So: LDS-DMA where A is row-contiguous, ODVAE_GEMM_DMA=1 / 0
+  // forces it on / off everywhere.
+  const int dma_env = dma_mode();
+  const bool dma = dma_env < 0 ? !a_kc : dma_env != 0;
+  if (dma) {
+    const int rc = a_kc && b_kc ? launch_dma(gemm_f32_dma_kernel<true, true>, grid, st, p)
+                 : a_kc         ? launch_dma(gemm_f32_dma_kernel<true, false>, grid, st, p)
+                 : b_kc         ? launch_dma(gemm_f32_dma_kernel<false, true>, grid, st, p)
+                                : launch_dma(gemm_f32_dma_kernel<false, false>, grid, st, p);
+    if (rc != ODVAE_OK) return rc;
+  }
+  else if (a_kc && b_kc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, p);
   else if (a_kc && !b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, p);
   else if (!a_kc && b_kc)  hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, p);
   else if (p.splits == 1 && batch > 1) hipLaunchKernelGGL((gemm_f32_kernel<false, false, false, true>), grid, block, 0, st, p);
@@ -400,7 +574,12 @@ int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha,
   p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
   p.rowsub = rowdot; p.emul = P; p.sRow = strideRow;
   dim3 grid(p.tiles_m * ceil_div(N, BN), 1, batch), block(256);
-  hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), grid, block, 0, static_cast<hipStream_t>(stream), p);
+  if (dma_mode() > 0) {
+    const int rc = launch_dma(gemm_f32_dma_kernel<true, true, true>, grid, static_cast<hipStream_t>(stream), p);
+    if (rc != ODVAE_OK) return rc;
+  } else {
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), grid, block, 0, static_cast<hipStream_t>(stream), p);
+  }
   ODVAE_LAUNCH_CHECK("gemm_softmax_bwd");
   return ODVAE_OK;
 }

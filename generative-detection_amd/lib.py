@@ -19,6 +19,7 @@ PROTOTYPES = {
     "odvae_abi_version": (_I, []),
     "odvae_target_arch": (_c.c_char_p, []),
     "odvae_gemm_f32_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "odvae_gemm_select_staging": (_I, [_I]),
     "odvae_gemm_f32": (_I, [_I, _I, _I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _P, _I, _P, _Z, _P]),
     "odvae_gemm_softmax_bwd_f32": (_I, [_I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _P, _L, _P, _I, _L, _I, _P]),
     "odvae_rowdot_f32": (_I, [_P, _P, _L, _I, _P, _P]),

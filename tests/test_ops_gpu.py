@@ -27,9 +27,18 @@ def dev():
 
 
 # ------------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[-1, 0, 1], ids=["staging-per-shape", "staging-registers", "staging-lds-dma"])
+def gemm_staging(request, hip_lib):
+    """Both operand-staging forms of gemm_f32.hip (and the per-shape default) under the GEMM-backed tests; they compute the same
+    products in the same order."""
+    prev = hip_lib.odvae_gemm_select_staging(request.param)
+    yield request.param
+    hip_lib.odvae_gemm_select_staging(prev)
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("m,n,k,batch", [(128, 128, 64, 1), (200, 72, 52, 3), (16, 16, 512, 2), (4, 260, 36, 1)])
-def test_gemm(hip_lib, ta, tb, m, n, k, batch):
+@pytest.mark.parametrize("m,n,k,batch", [(128, 128, 64, 1), (200, 72, 52, 3), (16, 16, 512, 2), (4, 260, 36, 1), (260, 132, 100, 2)])
+def test_gemm(hip_lib, gemm_staging, ta, tb, m, n, k, batch):
     from odvae_amd import ops
     if ta and m % 4:
         pytest.skip("transA needs M % 4 == 0")
@@ -56,7 +65,30 @@ def test_gemm(hip_lib, ta, tb, m, n, k, batch):
         ops.gemm(ta, tb, m, n, k, 0.5, ad, lda, sa, bd, ldb, sb, c2, n, m * n, biasd, resd, batch)
 
 
-def test_gemm_splitk(hip_lib):
+def test_gemm_staging_forms_are_bit_identical(hip_lib):
+    """Register-staged and LDS-DMA forms: same fragments, same MFMA order -- the results are equal bit for bit (all four layouts, a K
+    that is no multiple of the 32-wide step, ragged M / N, batch stride)."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(77)
+    m, n, k, batch = 260, 132, 100, 3
+    prev = hip_lib.odvae_gemm_select_staging(-1)
+    try:
+        for ta in (0, 1):
+            for tb in (0, 1):
+                a = torch.randn(batch, *((k, m) if ta else (m, k)), generator=g).to(dev())
+                b = torch.randn(batch, *((n, k) if tb else (k, n)), generator=g).to(dev())
+                outs = []
+                for mode in (0, 1):
+                    hip_lib.odvae_gemm_select_staging(mode)
+                    c = torch.empty(batch, m, n, device=dev())
+                    ops.gemm(ta, tb, m, n, k, 1.0, a, a.shape[2], a.shape[1] * a.shape[2], b, b.shape[2], b.shape[1] * b.shape[2], c, n, m * n, None, None, batch)
+                    outs.append(c)
+                assert torch.equal(outs[0], outs[1]), (ta, tb)
+    finally:
+        hip_lib.odvae_gemm_select_staging(prev)
+
+
+def test_gemm_splitk(hip_lib, gemm_staging):
     from odvae_amd import ops
     g = torch.Generator().manual_seed(7)
     m, n, k = 64, 96, 16384
@@ -347,7 +379,7 @@ def test_group_norm_skip_sums_both_gradients(hip_lib):
 
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 32, 64, 8, 8), (1, 128, 128, 16, 16), (3, 32, 16, 4, 4), (2, 16, 16, 4, 4)])
-def test_conv1x1(hip_lib, n, cin, cout, h, w):
+def test_conv1x1(hip_lib, gemm_staging, n, cin, cout, h, w):
     from odvae_amd import ops
     g = torch.Generator().manual_seed(cin * cout)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -370,7 +402,7 @@ def test_conv1x1(hip_lib, n, cin, cout, h, w):
 
 @pytest.mark.parametrize("fused", [True, False], ids=["softmax-bwd-in-gemm", "softmax-bwd-separate"])
 @pytest.mark.parametrize("n,c,h,w", [(2, 32, 4, 4), (2, 64, 16, 16), (1, 256, 8, 16), (2, 64, 10, 18)])
-def test_attention(hip_lib, monkeypatch, n, c, h, w, fused):
+def test_attention(hip_lib, gemm_staging, monkeypatch, n, c, h, w, fused):
     """fused: the softmax backward rides in the epilogue of the dP product (odvae_gemm_softmax_bwd_f32 + odvae_rowdot_f32);
     separate: bmm, then odvae_softmax_rows_bwd_f32.  (10 x 18 = 180 tokens: ragged 128-wide tiles on both axes.)"""
     from odvae_amd import ops
