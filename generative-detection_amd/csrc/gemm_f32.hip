@@ -31,9 +31,16 @@ constexpr int TILE_FLOATS = BM * LDS_KC;  // 4608 >= BK*LDS_RC = 4224
 // k quad q = q' ^ ((row >> 1) & 7), chosen by the per-lane GLOBAL address, the LDS side of the DMA being linear in the lane -- so the
 // 16 rows of a ds_read_b128 phase land on 16 different bank groups (even rows on banks 0-31, odd rows on 32-63, eight slots each).
 // A row-contiguous tile [32 k][128 rows] is read as b32 by 32 consecutive rows: conflict-free as it is.
-constexpr unsigned DMA_TILE_B = BM * BK * 4;        // 16 384
-constexpr unsigned DMA_STAGE_B = 2 * DMA_TILE_B;    // A then B
-constexpr unsigned DMA_LDS_B = 2 * DMA_STAGE_B;     // 65 536
+// Step width BKT = 32: 64 KB, two blocks per CU; BKT = 16: 32 KB, four blocks per CU (short-K products, where a block is mostly
+// prologue and store burst and more blocks per CU cover them); rows of 4 slots then swizzle with (row >> 2) & 3.
+template <int BKT> struct DmaGeom {
+  static constexpr unsigned TILE_B = BM * BKT * 4;      // 16 384 / 8 192
+  static constexpr unsigned STAGE_B = 2 * TILE_B;       // A then B
+  static constexpr unsigned LDS_B = 2 * STAGE_B;        // 65 536 / 32 768
+  static constexpr int SLOTS = BKT / 4;                 // 16-byte slots per row of a k-contiguous tile
+  static constexpr int PER_THREAD = BM * SLOTS / 256;   // DMA instructions per thread and operand: 4 / 2
+  static constexpr int ROW_SHIFT = BKT == 32 ? 3 : 2, SWZ_SHIFT = BKT == 32 ? 1 : 2, SWZ_MASK = SLOTS - 1;
+};
 __device__ __forceinline__ float lds_ld32(unsigned a) { return *(const __attribute__((address_space(3))) float*)(uintptr_t)a; }
 
 struct GemmParams {
@@ -89,7 +96,9 @@ struct TileFetch {
   }
   // ---- LDS-DMA form ----
   i32x4_t words;           // the same descriptor as raw dwords (inline asm operand)
+  template <int BKT>
   __device__ __forceinline__ void init_dma(const float* G, int ld, int row0, int nrows, int kbeg, int kend) {
+    typedef DmaGeom<BKT> D;
     const int tid = threadIdx.x;
     const unsigned OOB = 0x7FFFFFF0u;
     kvalid = kend - kbeg;
@@ -97,38 +106,43 @@ struct TileFetch {
       const int rows = min(BM, nrows - row0);
       const int64_t bytes = ((int64_t)(rows - 1) * ld + kvalid) * 4;
       words = rsrc_words(G + (int64_t)row0 * ld + kbeg, (unsigned)(bytes < 0x7FFFFFF0ll ? bytes : 0x7FFFFFF0ll));
-      step_bytes = BK * 4u;
+      step_bytes = BKT * 4u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < D::PER_THREAD; ++i) {
         const int f = tid + 256 * i;
-        const int row = f >> 3, q = (f & 7) ^ ((row >> 1) & 7);
+        const int row = f >> D::ROW_SHIFT, q = (f & D::SWZ_MASK) ^ ((row >> D::SWZ_SHIFT) & D::SWZ_MASK);
         voff[i] = (unsigned)((row * ld + 4 * q) * 4);
       }
     } else {
       const int64_t bytes = ((int64_t)(kvalid - 1) * ld + (nrows - row0)) * 4;
       words = rsrc_words(G + (int64_t)kbeg * ld + row0, (unsigned)(bytes < 0x7FFFFFF0ll ? bytes : 0x7FFFFFF0ll));
-      step_bytes = (unsigned)(BK * ld) * 4u;
+      step_bytes = (unsigned)(BKT * ld) * 4u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < D::PER_THREAD; ++i) {
         const int f = tid + 256 * i;
         voff[i] = (row0 + 4 * (f & 31) < nrows) ? (unsigned)(((f >> 5) * ld + 4 * (f & 31)) * 4) : OOB;
       }
     }
   }
   // tile of step `step` -> LDS at byte address `dst` (this operand's tile of the stage); slot f = tid + 256 i lands at dst + 16 f
+  template <int BKT>
   __device__ __forceinline__ void dma(int step, unsigned dst) const {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(step) * step_bytes;
-    const bool tail = KC && (step + 1) * BK > kvalid;
+    typedef DmaGeom<BKT> D;
+    i32x4_t w;      // the descriptor is wave-uniform; say so (an "s" asm operand that hipcc believes divergent is passed in VGPRs)
+    w.x = __builtin_amdgcn_readfirstlane(words.x); w.y = __builtin_amdgcn_readfirstlane(words.y);
+    w.z = __builtin_amdgcn_readfirstlane(words.z); w.w = __builtin_amdgcn_readfirstlane(words.w);
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)step * step_bytes));
+    const bool tail = KC && (step + 1) * BKT > kvalid;
     const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (threadIdx.x >> 6) * 1024u));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < D::PER_THREAD; ++i) {
       unsigned vo = voff[i];
       if (tail) {
         const int f = threadIdx.x + 256 * i;
-        const int q = (f & 7) ^ (((f >> 3) >> 1) & 7);
-        if (step * BK + 4 * q >= kvalid) vo = 0x7FFFFFF0u;
+        const int q = (f & D::SWZ_MASK) ^ (((f >> D::ROW_SHIFT) >> D::SWZ_SHIFT) & D::SWZ_MASK);
+        if (step * BKT + 4 * q >= kvalid) vo = 0x7FFFFFF0u;
       }
-      lds_dma16_s(words, (unsigned)__builtin_amdgcn_readfirstlane((int)(wbase + 4096u * i)), vo, soff);
+      lds_dma16_s(w, (unsigned)__builtin_amdgcn_readfirstlane((int)(wbase + 4096u * i)), vo, soff);
     }
   }
   // tile of step `step` (k = kbeg + step * BK ...)
@@ -171,14 +185,14 @@ __device__ __forceinline__ void read_frag(const float* S, int row, int g, int h,
   }
 }
 
-template <bool A_KC, bool B_KC, bool SMB, bool DMA>
+template <bool A_KC, bool B_KC, bool SMB, int DMA>     // DMA: 0 register-staged, else the step width of the LDS-DMA form
 __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem);
 
-// LDS-DMA form: 64 KB of dynamic LDS, two blocks per CU
-template <bool A_KC, bool B_KC, bool SMB = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(GemmParams p) {
+// LDS-DMA form: 64 KB of dynamic LDS and two blocks per CU at BKT = 32, 32 KB and four at BKT = 16
+template <bool A_KC, bool B_KC, bool SMB = false, int BKT = 32>
+__global__ __launch_bounds__(256, BKT == 32 ? 2 : (SMB ? 2 : 4)) void gemm_f32_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  gemm_body<A_KC, B_KC, SMB, true>(p, dsm);
+  gemm_body<A_KC, B_KC, SMB, BKT>(p, dsm);
 }
 
 template <bool A_KC, bool B_KC, bool SMB = false, bool OCC3 = (A_KC && B_KC && !SMB)>
@@ -188,10 +202,10 @@ template <bool A_KC, bool B_KC, bool SMB = false, bool OCC3 = (A_KC && B_KC && !
 // (tools/gemm_probe.py).
 __global__ __launch_bounds__(256, OCC3 ? 3 : 1) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
-  gemm_body<A_KC, B_KC, SMB, false>(p, smem);
+  gemm_body<A_KC, B_KC, SMB, 0>(p, smem);
 }
 
-template <bool A_KC, bool B_KC, bool SMB, bool DMA>
+template <bool A_KC, bool B_KC, bool SMB, int DMA>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
   float* As = smem;
   float* Bs = smem + TILE_FLOATS;
@@ -262,33 +276,36 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
 
-  if constexpr (DMA) {
+  if constexpr (DMA != 0) {
     // One barrier per step: the tiles of step s+1 are requested (LDS-DMA, inline asm: invisible to hipcc's vmcnt bookkeeping, awaited by
-    // hand) into the other stage at the top of step s and have its 64 MFMAs per wave to land.  Fragment addresses: one VGPR per
-    // (operand, k group) computed once; stage and tile are immediates (the loop body is written out for both stages).
+    // hand) into the other stage at the top of step s and have its MFMAs to land.  Fragment addresses: one VGPR per (operand, k group)
+    // computed once; stage and tile are immediates (the loop body is written out for both stages).
+    constexpr int BKT = DMA == 0 ? 32 : DMA;
+    typedef DmaGeom<BKT> D;
     const unsigned lds0 = lds_addr_of(smem);
     TileFetch<A_KC> fa;
     TileFetch<B_KC> fb;
-    const int nsteps = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    const int nsteps = kbeg < kend ? (kend - kbeg + BKT - 1) / BKT : 0;
     if (nsteps > 0) {
-      fa.init_dma(A, p.lda, m0, p.M, kbeg, kend);
-      fb.init_dma(B, p.ldb, n0, p.N, kbeg, kend);
-      fa.dma(0, lds0);
-      fb.dma(0, lds0 + DMA_TILE_B);
+      fa.template init_dma<BKT>(A, p.lda, m0, p.M, kbeg, kend);
+      fb.template init_dma<BKT>(B, p.ldb, n0, p.N, kbeg, kend);
+      fa.template dma<BKT>(0, lds0);
+      fb.template dma<BKT>(0, lds0 + D::TILE_B);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned hs = (unsigned)(h ^ ((li >> 1) & 7));
-    unsigned adrA[4], adrB[4];      // KC: row base + swizzled slot of k group g; row-contiguous: one base (adr[0])
+    const unsigned hs = (unsigned)(h ^ ((li >> D::SWZ_SHIFT) & D::SWZ_MASK));
+    constexpr int NG = BKT / 8;
+    unsigned adrA[NG], adrB[NG];      // KC: row base + swizzled slot of k group g; row-contiguous: one base (adr[0])
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      adrA[g] = A_KC ? lds0 + (unsigned)((wm * 64 + li) * 128) + ((hs ^ (2u * g)) << 4) : lds0 + (unsigned)((4 * h * 128 + wm * 64 + li) * 4);
-      adrB[g] = B_KC ? lds0 + DMA_TILE_B + (unsigned)((wn * 64 + li) * 128) + ((hs ^ (2u * g)) << 4)
-                     : lds0 + DMA_TILE_B + (unsigned)((4 * h * 128 + wn * 64 + li) * 4);
+    for (int g = 0; g < NG; ++g) {
+      adrA[g] = A_KC ? lds0 + (unsigned)((wm * 64 + li) * (BKT * 4)) + ((hs ^ (2u * g)) << 4) : lds0 + (unsigned)((4 * h * 128 + wm * 64 + li) * 4);
+      adrB[g] = B_KC ? lds0 + D::TILE_B + (unsigned)((wn * 64 + li) * (BKT * 4)) + ((hs ^ (2u * g)) << 4)
+                     : lds0 + D::TILE_B + (unsigned)((4 * h * 128 + wn * 64 + li) * 4);
     }
-    auto frag = [&](auto kc, const unsigned (&adr)[4], unsigned stage_b, int g, int t, float (&v)[4]) {
+    auto frag = [&](auto kc, const unsigned (&adr)[NG], unsigned stage_b, int g, int t, float (&v)[4]) {
       if constexpr (decltype(kc)::value) {
-        const f32x4 x = lds_ld128f(adr[g] + stage_b + (unsigned)(t * 32 * 128));
+        const f32x4 x = lds_ld128f(adr[g] + stage_b + (unsigned)(t * 32 * BKT * 4));
         v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
       } else {
 #pragma unroll
@@ -296,13 +313,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
       }
     };
     auto body = [&](auto stage, int step) {
-      constexpr unsigned ST = decltype(stage)::value * DMA_STAGE_B;
+      constexpr unsigned ST = decltype(stage)::value * D::STAGE_B;
       if (step + 1 < nsteps) {
-        fa.dma(step + 1, lds0 + (DMA_STAGE_B - ST));
-        fb.dma(step + 1, lds0 + (DMA_STAGE_B - ST) + DMA_TILE_B);
+        fa.template dma<BKT>(step + 1, lds0 + (D::STAGE_B - ST));
+        fb.template dma<BKT>(step + 1, lds0 + (D::STAGE_B - ST) + D::TILE_B);
       }
 #pragma unroll
-      for (int g = 0; g < BK / 8; ++g) {
+      for (int g = 0; g < NG; ++g) {
         float a[2][4], b[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -434,11 +451,15 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
 // ODVAE_GEMM_DMA: unset = per shape (see odvae_gemm_f32), 1 = LDS-DMA form everywhere, 0 = register-staged form everywhere
 int g_dma_mode = -2;      // -2: environment not read yet
 int dma_mode() {
-  if (g_dma_mode == -2) g_dma_mode = getenv("ODVAE_GEMM_DMA") == nullptr ? -1 : (atoi(getenv("ODVAE_GEMM_DMA")) != 0 ? 1 : 0);
+  if (g_dma_mode == -2) {
+    const int v = getenv("ODVAE_GEMM_DMA") == nullptr ? -1 : atoi(getenv("ODVAE_GEMM_DMA"));
+    g_dma_mode = v < 0 ? -1 : (v > 2 ? 2 : v);
+  }
   return g_dma_mode;
 }
 template <typename K>
-int launch_dma(K kern, dim3 grid, hipStream_t st, const GemmParams& p) {
+int launch_dma(K kern, dim3 grid, hipStream_t st, const GemmParams& p, unsigned lds_bytes = DmaGeom<32>::LDS_B) {
+  const unsigned DMA_LDS_B = lds_bytes;
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_B);
   if (e != hipSuccess) {
     odvae_set_error("gemm_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -465,10 +486,10 @@ extern "C" {
 
 // Operand staging of odvae_gemm_f32 / odvae_gemm_softmax_bwd_f32: -1 per shape (default), 0 through registers (global -> VGPR -> ds_write,
 // one LDS stage, up to three blocks per CU), 1 by LDS-DMA (two stages, one barrier per step).  ODVAE_GEMM_DMA presets it.  Returns the
-// previous setting.  Results are identical (same products, same summation order).
+// previous setting; 2 = LDS-DMA with 16-wide steps (32 KB, four blocks per CU).  Results are identical (same products, same summation order).
 int odvae_gemm_select_staging(int mode) {
   const int prev = dma_mode();
-  g_dma_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  g_dma_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
   return prev;
 }
 
@@ -526,12 +547,19 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   // cost the third block per CU that covers prologue and store bursts.  So: LDS-DMA where A is row-contiguous, ODVAE_GEMM_DMA=1 / 0
   // forces it on / off everywhere.
   const int dma_env = dma_mode();
-  const bool dma = dma_env < 0 ? !a_kc : dma_env != 0;
-  if (dma) {
+  const int bkt = dma_env < 0 ? (!a_kc ? 32 : 0) : (dma_env == 0 ? 0 : (dma_env == 2 ? 16 : 32));
+  if (bkt == 32) {
     const int rc = a_kc && b_kc ? launch_dma(gemm_f32_dma_kernel<true, true>, grid, st, p)
                  : a_kc         ? launch_dma(gemm_f32_dma_kernel<true, false>, grid, st, p)
                  : b_kc         ? launch_dma(gemm_f32_dma_kernel<false, true>, grid, st, p)
                                 : launch_dma(gemm_f32_dma_kernel<false, false>, grid, st, p);
+    if (rc != ODVAE_OK) return rc;
+  } else if (bkt == 16) {
+    const unsigned lb = DmaGeom<16>::LDS_B;
+    const int rc = a_kc && b_kc ? launch_dma(gemm_f32_dma_kernel<true, true, false, 16>, grid, st, p, lb)
+                 : a_kc         ? launch_dma(gemm_f32_dma_kernel<true, false, false, 16>, grid, st, p, lb)
+                 : b_kc         ? launch_dma(gemm_f32_dma_kernel<false, true, false, 16>, grid, st, p, lb)
+                                : launch_dma(gemm_f32_dma_kernel<false, false, false, 16>, grid, st, p, lb);
     if (rc != ODVAE_OK) return rc;
   }
   else if (a_kc && b_kc)   hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, p);
@@ -574,7 +602,10 @@ int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha,
   p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
   p.rowsub = rowdot; p.emul = P; p.sRow = strideRow;
   dim3 grid(p.tiles_m * ceil_div(N, BN), 1, batch), block(256);
-  if (dma_mode() > 0) {
+  if (dma_mode() == 2) {
+    const int rc = launch_dma(gemm_f32_dma_kernel<true, true, true, 16>, grid, static_cast<hipStream_t>(stream), p, DmaGeom<16>::LDS_B);
+    if (rc != ODVAE_OK) return rc;
+  } else if (dma_mode() == 1) {
     const int rc = launch_dma(gemm_f32_dma_kernel<true, true, true>, grid, static_cast<hipStream_t>(stream), p);
     if (rc != ODVAE_OK) return rc;
   } else {

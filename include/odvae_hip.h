@@ -42,7 +42,8 @@ const char* odvae_target_arch(void);  /* "gfx950" */
  * post_quant_conv: src/models/autoencoder.py:88-90,179-180) and AttnBlock's torch.bmm products. */
 size_t odvae_gemm_f32_workspace_bytes(int M, int N, int K, int batch);
 /* operand staging of the two GEMM entry points: -1 per shape (default: LDS-DMA where A is row-contiguous), 0 through registers,
- * 1 by LDS-DMA (`buffer_load ... lds`, two stages); identical results; returns the previous setting.  Env preset: ODVAE_GEMM_DMA. */
+ * 1 by LDS-DMA (`buffer_load ... lds`, two stages of 32-wide steps), 2 the same with 16-wide steps (four blocks per CU); identical
+ * results; returns the previous setting.  Env preset: ODVAE_GEMM_DMA. */
 int odvae_gemm_select_staging(int mode);
 int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                    const float* A, int lda, int64_t strideA,

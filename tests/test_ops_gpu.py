@@ -27,7 +27,7 @@ def dev():
 
 
 # ------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[-1, 0, 1], ids=["staging-per-shape", "staging-registers", "staging-lds-dma"])
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["staging-per-shape", "staging-registers", "staging-lds-dma-32", "staging-lds-dma-16"])
 def gemm_staging(request, hip_lib):
     """Both operand-staging forms of gemm_f32.hip (and the per-shape default) under the GEMM-backed tests; they compute the same
     products in the same order."""
@@ -66,7 +66,7 @@ def test_gemm(hip_lib, gemm_staging, ta, tb, m, n, k, batch):
 
 
 def test_gemm_staging_forms_are_bit_identical(hip_lib):
-    """Register-staged and LDS-DMA forms: same fragments, same MFMA order -- the results are equal bit for bit (all four layouts, a K
+    """Register-staged and LDS-DMA forms (32- and 16-wide steps): same fragments, same MFMA order -- the results are equal bit for bit (all four layouts, a K
     that is no multiple of the 32-wide step, ragged M / N, batch stride)."""
     from odvae_amd import ops
     g = torch.Generator().manual_seed(77)
@@ -78,12 +78,12 @@ def test_gemm_staging_forms_are_bit_identical(hip_lib):
                 a = torch.randn(batch, *((k, m) if ta else (m, k)), generator=g).to(dev())
                 b = torch.randn(batch, *((n, k) if tb else (k, n)), generator=g).to(dev())
                 outs = []
-                for mode in (0, 1):
+                for mode in (0, 1, 2):
                     hip_lib.odvae_gemm_select_staging(mode)
                     c = torch.empty(batch, m, n, device=dev())
                     ops.gemm(ta, tb, m, n, k, 1.0, a, a.shape[2], a.shape[1] * a.shape[2], b, b.shape[2], b.shape[1] * b.shape[2], c, n, m * n, None, None, batch)
                     outs.append(c)
-                assert torch.equal(outs[0], outs[1]), (ta, tb)
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (ta, tb)
     finally:
         hip_lib.odvae_gemm_select_staging(prev)
 
