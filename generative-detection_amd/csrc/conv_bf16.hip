@@ -599,6 +599,197 @@ __global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 128 x 128 register tiles: block = 16 x 32 output pixels x 128 output channels, FOUR waves (one per SIMD; the 256 accumulator
+// registers of a 4 x 4 grid of MFMA tiles each, in AGPRs), 16 input channels per chunk.
+//
+// Why this shape.  (1) Every LDS-staged variant above paid for its LDS-DMA pieces: a `buffer_load ... lds` costs the issuing wave
+// 60-185 cycles (MI355X_MICROARCH.md), and weights + halo through LDS are 48-56 pieces per chunk -- 30-50 % of the chunk's MFMA time.
+// (2) A weight fragment (1 KiB per tap, 16 ci, 32 co) fetched straight from L2 into registers costs one vector-memory instruction
+// that hides in an MFMA gap, but with 64 x 64 wave tiles it feeds two MFMAs only and the weight stream of a whole chip nears the L2's
+// bandwidth.  Here a fragment feeds FOUR MFMAs (four pixel tiles per wave), the chunk's 36 fragments live in 144 VGPRs and are
+// refilled in place for the next chunk right behind their last use, and only the halo (18 x 34 pixels x 16 channels: five pieces per
+// wave) goes through LDS, two chunks ahead in a ring of three 20 KiB stages.  (3) vmcnt retires in order: all vector memory of the
+// loop is issued from inline asm and awaited by hand -- a fragment with exactly the 32 younger refills + 5 halo pieces in flight, the
+// halo of the next chunk with the 36 refills + 5 pieces issued since.
+// ------------------------------------------------------------------------------------------------------------------------
+// -DODVAE_BIG_ABL=<bits>: timing-only ablations (wrong results): 1 no weight refills / waits, 2 no halo DMA / wait, 4 no barrier, 8 pixel fragments read once per chunk
+#ifndef ODVAE_BIG_ABL
+#define ODVAE_BIG_ABL 0
+#endif
+__global__ __launch_bounds__(256) void conv_bf16_big_kernel(ConvB p) {
+  constexpr int TAPS = 9, TH = 16, TWB = 32, HWB = TWB + 2, HPIX = (TH + 2) * HWB;
+  constexpr int HPIECES = (HPIX * 2 + 63) / 64;       // 20 halo pieces per chunk
+  static_assert(HPIECES % 4 == 0, "whole pieces per wave");
+  constexpr int HPW = HPIECES / 4;                    // five per wave
+  constexpr unsigned HSTAGE = HPIECES * 1024;
+  constexpr int WCT = 4, WPT = 4, NFR = TAPS * WCT;   // 36 weight fragments per chunk
+  extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
+  const unsigned lds0 = lds_addr_of(smem);
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int wpx = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TWB;
+  const int co0 = blockIdx.y * 128;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int esz = p.out_f32 ? 4 : 2;
+  const unsigned OOB = 0x7FFFFFF0u;
+  const int KT = p.CinP / 16, CT = p.CoutP / 32;
+  const int nchunks = KT;
+
+  const i32x4_t xw = rsrc_words(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin, (unsigned)(p.Hi * p.Wi * p.Cin * 2));
+  const i32x4_t ww = rsrc_words(p.wpk, (unsigned)(TAPS * KT * CT * 1024));
+  unsigned hvoff[HPW];
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    const int slot = 64 * (wpx + 4 * q) + lane;
+    const int px = slot >> 1, half = (slot & 1) ^ ((px >> 3) & 1);
+    const int iy = iy0 + px / HWB, ix = ix0 + px % HWB;
+    const bool ok = px < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    hvoff[q] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * half) * 2) : OOB;
+  }
+  const unsigned lane16 = lane * 16;
+  // halo pieces of chunk kt -> stage hst; past the last chunk the same five instructions run against an empty descriptor (zeros land
+  // in a stage nobody reads any more), so that the number of operations in flight is the same in every chunk
+  auto issue_h = [&](int kt, unsigned hst) {
+    i32x4_t r = xw;
+    r.z = kt < nchunks ? xw.z : 0;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(kt < nchunks ? kt * 32 : 0);
+#pragma unroll
+    for (int q = 0; q < HPW; ++q)
+      lds_dma16_s(r, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + hst + 1024u * (wpx + 4 * q))), hvoff[q], soff);
+  };
+  // weight fragment (tap, ct) of chunk kt -> registers
+  u32x4 wf[TAPS][WCT];
+  auto load_w = [&](int kt, int tap, int ct, u32x4& dst) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((tap * KT + kt) * CT + co0 / 32 + ct) * 1024);
+    // (no s_nop in front: `soff` is the result of scalar arithmetic here -- the kernel has no SGPR spills, checked in the build's
+    // register statistics -- and the four MFMAs in front of every refill cover a VALU write anyway)
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(lane16), "s"(ww), "s"(soff) : "memory");
+  };
+  issue_h(0, 0);
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct) load_w(0, tap, ct, wf[tap][ct]);
+  issue_h(1, HSTAGE);
+
+  // this lane's pixel in each of its four pixel tiles (one tile = one row of 32 pixels; column of the MFMA result)
+  unsigned pixoff[WPT];
+  unsigned hp0[WPT];
+#pragma unroll
+  for (int pt = 0; pt < WPT; ++pt) {
+    const int pr = wpx * WPT + pt, pc = li;
+    const int oy = oy0 + pr, ox = ox0 + pc;
+    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
+    hp0[pt] = (unsigned)(pr * HWB + pc);
+  }
+
+  // With one wave per SIMD nothing hides a long prologue: the accumulators start at zero (bias and residual join in the epilogue, whose
+  // loads are requested in batches)
+  f32x16 acc[WCT][WPT];
+#pragma unroll
+  for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < WPT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+
+  auto load_px = [&](unsigned ha, int tap, bf16x8 (&b)[WPT]) {
+    const unsigned toff = (unsigned)((tap / 3) * HWB + (tap % 3));
+#pragma unroll
+    for (int pt = 0; pt < WPT; ++pt) {
+      const unsigned px = hp0[pt] + toff;
+      b[pt] = frag_from_u32x4(lds_ld128(ha + px * 32u + ((((px >> 3) ^ (unsigned)h) & 1u) << 4)));
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW) : "memory");      // halo 0 and the 36 fragments (the five pieces of halo 1 stay in flight)
+  __syncthreads();
+  unsigned hcur = 0, hnxt = HSTAGE, hfre = 2 * HSTAGE;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int chn = ch + 1 < nchunks ? ch + 1 : 0;               // past the last chunk: a harmless reload
+    const unsigned ha = lds0 + hcur;
+    bf16x8 bbuf[2][WPT];
+    load_px(ha, 0, bbuf[0]);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      if (tap + 1 < TAPS && !(ODVAE_BIG_ABL & 8)) load_px(ha, tap + 1, bbuf[(tap + 1) & 1]);
+      if (ODVAE_BIG_ABL & 8) { for (int pt = 0; pt < WPT; ++pt) bbuf[(tap + 1) & 1][pt] = bbuf[tap & 1][pt]; }
+      // fragments of this tap: requested one chunk ago; younger than them: 4 (8 - tap) refills + 5 halo pieces + 4 tap refills = 37
+      if (!(ODVAE_BIG_ABL & 3))
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wf[tap][0]), "+v"(wf[tap][1]), "+v"(wf[tap][2]), "+v"(wf[tap][3]) : "n"(NFR - WCT + HPW) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < WCT; ++ct) {      // four MFMAs per fragment, its refill for the next chunk right behind them
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(frag_from_u32x4(wf[tap][ct]), bbuf[tap & 1][pt], acc[ct][pt]);
+        if (!(ODVAE_BIG_ABL & 1)) load_w(chn, tap, ct, wf[tap][ct]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!(ODVAE_BIG_ABL & 2)) issue_h(ch + 2, hfre);          // the stage chunk ch - 1 read: its reads ended before the barrier above
+    { const unsigned o = hcur; hcur = hnxt; hnxt = hfre; hfre = o; }
+    if (ODVAE_BIG_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFR + HPW) : "memory");      // halo ch+1 (older than this chunk's 36 refills + 5 pieces) has landed
+    if (!(ODVAE_BIG_ABL & 4)) __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the refills past the last chunk still write registers
+
+  // ---- epilogue: bias (one 16-byte load per (channel tile, quad)) and residual requested in batches, then stores -----------------
+  const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      static_cast<char*>(p.y) + img * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.bias ? p.bias : reinterpret_cast<const float*>(p.x)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+  for (int ct = 0; ct < WCT; ++ct) {
+    u32x4 bq[4];
+    u32x2 rq[4][WPT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + ct * 32 + 8 * g + 4 * h;
+      bq[g] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, co < p.Cout ? (unsigned)co * 4u : OOB, 0, 0);     // (Cout % 4 == 0: whole quads)
+#pragma unroll
+      for (int pt = 0; pt < WPT; ++pt) rq[g][pt] = u32x2{0u, 0u};
+      if (p.residual) {
+#pragma unroll
+        for (int pt = 0; pt < WPT; ++pt)
+          rq[g][pt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + ct * 32 + 8 * g + 4 * h;
+      const float b0 = __uint_as_float(bq[g].x), b1 = __uint_as_float(bq[g].y), b2 = __uint_as_float(bq[g].z), b3 = __uint_as_float(bq[g].w);
+#pragma unroll
+      for (int pt = 0; pt < WPT; ++pt) {
+        const float v0 = acc[ct][pt][4 * g + 0] + b0 + bf16_lo(rq[g][pt].x), v1 = acc[ct][pt][4 * g + 1] + b1 + bf16_hi(rq[g][pt].x);
+        const float v2 = acc[ct][pt][4 * g + 2] + b2 + bf16_lo(rq[g][pt].y), v3 = acc[ct][pt][4 * g + 3] + b3 + bf16_hi(rq[g][pt].y);
+        if (p.out_f32) {
+          const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[j]), yrsrc, off, 0, 0);
+          }
+        } else {
+          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+          u32x2 v;
+          v.x = pack_bf16x2(v0, v1);
+          v.y = pack_bf16x2(v2, v3);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // OIHW f32 (kh x kw = 3x3 or 1x1) -> bf16 fragment packs.
 //   fwd:   reduce over Cin, rows = Cout:   W[tap][co][ci]
 //   dgrad: reduce over Cout, rows = Cin:   W'[tap][ci][co] = w[co][ci][flip(tap)]   (MODE 0 / 4 data gradient; MODE 3 uses
@@ -666,7 +857,7 @@ extern "C" {
 // Tile of the stride-1 3x3 convs with Cout > 64 and Ho >= 16: 0 = 8 x 16 pixels (conv_bf16_kernel), 1 = 16 x 16 with an LDS-DMA halo
 // ring and weights from L2 (conv_bf16_wide_kernel, Cin % 32 == 0), 2 = 16 x 16 with weights AND halo through LDS
 // (conv_bf16_lds_kernel, Cin % 16 == 0).  ODVAE_CONV_BF16_WIDE2 presets it.  Returns the previous setting (-1 = environment not read yet).
-int odvae_conv_bf16_select_wide_tile(int on) { const int prev = g_wide_tile; g_wide_tile = on < 0 ? 0 : (on > 2 ? 2 : on); return prev; }
+int odvae_conv_bf16_select_wide_tile(int on) { const int prev = g_wide_tile; g_wide_tile = on < 0 ? 0 : (on > 3 ? 3 : on); return prev; }
 
 // reduction-channel padding (16 per MFMA k-step; the kernel walks chunks of 32 or 64) and output-channel padding of a pack
 int odvae_conv_bf16_reduce_pad(int c) { return c % 64 == 0 ? c : pad_to(c, 32); }
@@ -729,6 +920,20 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   // conv_bf16_kernel.  The structural fix is weights through LDS as well (no per-step global loads); DESIGN.md 9.
   if (g_wide_tile < 0) g_wide_tile = getenv("ODVAE_CONV_BF16_WIDE2") ? atoi(getenv("ODVAE_CONV_BF16_WIDE2")) : 0;
   const int wide2 = g_wide_tile;
+  if (mode == 0 && wide2 == 3 && Cout > 64 && Cout % 4 == 0 && Cin % 16 == 0 && Ho >= 16 && Wo >= 32) {
+    p.tiles_x = ceil_div(Wo, 32);
+    p.tiles_y = ceil_div(Ho, 16);
+    constexpr int lds_bytes = 3 * 20 * 1024;
+    static bool once_b = false;
+    if (!once_b) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      once_b = true;
+    }
+    ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
+    hipLaunchKernelGGL(conv_bf16_big_kernel, dim3(N * p.tiles_x * p.tiles_y, ceil_div(Cout, 128)), dim3(256), lds_bytes, st, p);
+    ODVAE_LAUNCH_CHECK("conv_bf16 (128 x 128 register tiles)");
+    return ODVAE_OK;
+  }
   if (mode == 0 && wide2 == 2 && Cout > 64 && Cin % 16 == 0 && Ho >= 16) {
     p.tiles_y = ceil_div(Ho, 16);
     constexpr int lds_bytes = 3 * 48 * 1024;

@@ -54,7 +54,7 @@ def ref_conv(mode, x, w, b):
     # the wide tile (16 x 16 pixels x 128 channels, LDS-DMA halo ring): whole tiles, ragged tiles in both directions, one / two / four
     # 32-channel chunks, two output-channel blocks, forward and (Cin > 64) data gradient
     (0, 2, 128, 128, 32, 32), (0, 1, 256, 256, 20, 36), (0, 1, 128, 256, 17, 16), (0, 3, 32, 128, 16, 48), (0, 1, 96, 192, 33, 18)])
-@pytest.mark.parametrize("wide", [0, 1, 2], ids=["tile8x16", "tile16x16", "tile16x16-lds"])
+@pytest.mark.parametrize("wide", [0, 1, 2, 3], ids=["tile8x16", "tile16x16", "tile16x16-lds", "tile16x32-128x128regs"])
 def test_conv_bf16_fwd_bwd(hip_lib, mode, n, cin, cout, h, w, wide):
     from odvae_amd import ops
     if wide and not (mode == 0 and max(cin, cout) > 64 and h >= 16):
