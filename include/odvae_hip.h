@@ -242,7 +242,8 @@ int odvae_linear_bwd_f32(const float* x, const float* w, const float* pre, const
 
 /* ---- conv_bf16.hip: 3x3 / 1x1 convolutions ([UPSTREAM] ldm model.py via feat_encoder.py:4, feat_decoder.py:4) ---------------- */
 /* Tile of the stride-1 3x3 convs with Cout > 64 and Ho >= 16: 0 = 8x16 pixels; 1 = 16x16 pixels, LDS-DMA halo ring, weights from L2
-   (Cin % 32 == 0); 2 = 16x16 pixels, weights and halo through LDS (Cin % 16 == 0).  Returns the previous setting (-1: not chosen yet,
+   (Cin % 32 == 0); 2 = 16x16 pixels, weights and halo through LDS (Cin % 16 == 0); 3 = 16x32 pixels on 128x128 register tiles
+   (four waves, Cin % 16 == 0, Wo >= 32).  Returns the previous setting (-1: not chosen yet,
    the environment variable ODVAE_CONV_BF16_WIDE2 decides at the first call). */
 int odvae_conv_bf16_select_wide_tile(int on);
 int odvae_conv_bf16_reduce_pad(int c);
