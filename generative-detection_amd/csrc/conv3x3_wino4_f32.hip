@@ -50,6 +50,8 @@ struct Wino4Params {
   float* y;               // [N][H][W][Cout]
   int N, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, act, xcd;
   int persist;            // 1: 1-D grid of one block per CU, every block walks a sequence of tiles of one output-channel block
+  float* gn_partial;      // [N][tiles per image][gn_groups][2] (sum, sum of squares of y per tile and channel group) or null
+  int gn_groups, gn_cpg;  // channel groups of the GroupNorm that reads y, channels per group (a power of two <= 32)
 };
 
 __device__ __forceinline__ f32x2 lds_ld64f(unsigned a) { return *(const __attribute__((address_space(3))) f32x2*)(uintptr_t)a; }
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   const int cstep = p.Cout * 4, rstep = p.W * p.Cout * 4;
   const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane_e) * 4);
   const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane_e) * 4);
+  float gsum = 0.f, gsq = 0.f;      // GroupNorm statistics of this thread's outputs (p.gn_partial)
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
@@ -336,10 +339,41 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       for (int a = 0; a < 4; ++a)
         if (!(ODVAE_W4_ABL & 128) || yv[a] == 12345.678f)
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
+      if (p.gn_partial && base != OOB) {      // (a 4x4 tile is inside the image as a whole: H and W are multiples of 4)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { gsum += yv[a]; gsq += yv[a] * yv[a]; }
+      }
     }
     // the next tile's halo: with a residual the 16 loads + 16 stores of pass 0 are younger than it, without one the 32 stores of passes 0, 1
     if (has_next && rq == (p.residual ? 0 : 1)) wait_vm_but<32>();
     if (rq < 3 && !(ODVAE_W4_ABL & 512)) __syncthreads();     // X is rewritten by the next pass
+  }
+  // ---- GroupNorm statistics of this tile for the layer that reads y: (sum, sum of squares) per channel group, one slot per
+  // (image, tile, group) written by exactly one block -- the consumer's finalize kernel adds the tiles up in f64, in fixed order ----
+  if (p.gn_partial) {
+    const int cpg = p.gn_cpg;
+    gsum += __shfl_xor(gsum, 32, 64); gsq += __shfl_xor(gsq, 32, 64);          // the two tile columns of a lane pair
+    for (int o = 1; o < cpg; o <<= 1) { gsum += __shfl_xor(gsum, o, 64); gsq += __shfl_xor(gsq, o, 64); }   // the channels of a group
+    __syncthreads();                 // the last pass's reads of X are done: its first 2 KB become the exchange area S[e2][ct2][32][2]
+    if (h_e == 0 && (li_e & (cpg - 1)) == 0) {
+      lds_st32f(X0 + (unsigned)((((wave >> 1) * 2 + ct2) * 32 + li_e) * 8), gsum);
+      lds_st32f(X0 + (unsigned)((((wave >> 1) * 2 + ct2) * 32 + li_e) * 8 + 4), gsq);
+    }
+    __syncthreads();
+    if (tid < 64 && (tid & (cpg - 1)) == 0) {       // thread = (co tile tid >> 5, first lane of a group)
+      const int ctq = tid >> 5, l = tid & 31, cg = n0 + ctq * 32 + l;
+      if (cg < p.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a += lds_ld32f(X0 + (unsigned)(((e * 2 + ctq) * 32 + l) * 8));
+          b += lds_ld32f(X0 + (unsigned)(((e * 2 + ctq) * 32 + l) * 8 + 4));
+        }
+        const int tile_in_image = (oy0 / TH) * p.tiles_x + ox0 / TW;
+        float* dst = p.gn_partial + (((int64_t)n * (p.tiles_x * p.tiles_y) + tile_in_image) * p.gn_groups + cg / cpg) * 2;
+        dst[0] = a; dst[1] = b;
+      }
+    }
   }
   if (!has_next) break;
   s_cur = s_nxt;
@@ -437,10 +471,33 @@ int odvae_conv3x3_pack_wino4_f32(const float* w, int Cout, int Cin, float* fwd_p
   return ODVAE_OK;
 }
 
+// tiles per image of the F(4x4) kernel = the chunk count of its GroupNorm partials
+int odvae_conv3x3_wino4_stats_chunks(int H, int W) { return ceil_div(H, TH) * ceil_div(W, TW); }
+
+static int wino4_launch(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream);
+
 // y = conv3x3_stride1_pad1(x) (+bias) (+residual); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino4_f32; act must be 0
 // (a fused ReLU is not offered: ops.py keeps the ReLU convs of the VGG stack on F(2x2) for accuracy, see there).
 int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
                             const float* bias, const float* residual, float* y, int act, void* stream) {
+  return wino4_launch(x, N, H, W, Cin, upk, Cout, bias, residual, y, act, nullptr, 0, stream);
+}
+
+// The same, and the output transform also leaves the GroupNorm statistics of y for the layer that reads it:
+// gn_partial [N][odvae_conv3x3_wino4_stats_chunks(H, W)][gn_groups][2] = (sum, sum of squares) of y per tile and channel group
+// (every slot written, by exactly one block) -- the input of odvae_groupnorm_fwd_partials_f32, which then needs no statistics pass.
+// Cout / gn_groups must be a power of two <= 32.
+int odvae_conv3x3_wino4_stats_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                                  const float* bias, const float* residual, float* y, float* gn_partial, int gn_groups, void* stream) {
+  ODVAE_CHECK_ARG(gn_partial && gn_groups > 0 && Cout % gn_groups == 0, "conv3x3_wino4_stats: bad statistics arguments");
+  const int cpg = Cout / gn_groups;
+  ODVAE_CHECK_ARG(cpg <= 32 && (cpg & (cpg - 1)) == 0, "conv3x3_wino4_stats: %d channels per group (needs a power of two <= 32)", cpg);
+  return wino4_launch(x, N, H, W, Cin, upk, Cout, bias, residual, y, 0, gn_partial, gn_groups, stream);
+}
+
+static int wino4_launch(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream) {
   ODVAE_CHECK_ARG(x && upk && y, "conv3x3_wino4: null operand");
   ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino4: empty shape");
   ODVAE_CHECK_ARG(act == 0, "conv3x3_wino4: no fused activation (act=%d); ReLU convs stay on odvae_conv3x3_wino_f32", act);
@@ -453,6 +510,7 @@ int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const 
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.CinP = odvae_conv3x3_wino4_reduce_pad(Cin); p.CoutP = odvae_conv3x3_wino4_out_pad(Cout);
   p.tiles_x = ceil_div(W, TW); p.tiles_y = ceil_div(H, TH); p.act = act;
+  p.gn_partial = gn_partial; p.gn_groups = gn_groups; p.gn_cpg = gn_groups > 0 ? Cout / gn_groups : 0;
   ODVAE_CHECK_ARG((int64_t)36 * p.CinP * p.CoutP * 4 < 0x7FFFFFF0ll, "conv3x3_wino4: pack too large");
   const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino4: too many tiles");

@@ -291,6 +291,29 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
   return ODVAE_OK;
 }
 
+// The same with the statistics pass already done by the kernel that produced x: partial [N][chunks][G][2] = (sum, sum of squares) of x
+// per chunk and channel group (odvae_conv3x3_wino4_stats_f32 writes one chunk per output tile).  Two launches instead of three: finalize
+// (f64, fixed order over the chunks) + apply; x is read once.
+int odvae_groupnorm_fwd_partials_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                                     float eps, int swish, float* y, float* mean, float* rstd,
+                                     const float* partial, int chunks, void* stream) {
+  GnShape s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_fwd_partials: unsupported shape N=%d HW=%d C=%d G=%d (need C%%G==0, C%%4==0, C<=1024)", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && gamma && beta && y && mean && rstd && partial && chunks > 0, "groupnorm_fwd_partials: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0 &&
+                  ((uintptr_t)partial & 7) == 0, "groupnorm_fwd_partials: operands must be 16-byte aligned (partial: 8)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GnShape sf = s;
+  sf.chunks = chunks;
+  hipLaunchKernelGGL(gn_finalize_kernel<GnShape>, dim3(ceil_div(N * G, 4)), dim3(256), 0, st, partial, sf, eps, mean, rstd);
+  ODVAE_LAUNCH_CHECK("groupnorm finalize (partials)");
+  const dim3 grid(apply_blocks(s), N);
+  if (swish) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  else       hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  ODVAE_LAUNCH_CHECK("groupnorm apply");
+  return ODVAE_OK;
+}
+
 // dx, dgamma[C], dbeta[C] from dy (gradient w.r.t. the activated output), x and the saved mean/rstd
 int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,

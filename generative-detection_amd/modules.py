@@ -36,8 +36,10 @@ class Conv3x3(nn.Conv2d):
         super().__init__(cin, cout, kernel_size=3, stride=stride, padding=pad)
         self.mode = mode
 
-    def forward(self, x, residual=None, out_f32=False):
-        return ops.conv3x3(x, self.weight, self.bias, residual, self.mode, out_f32=out_f32)
+    def forward(self, x, residual=None, out_f32=False, gn_stats=False):
+        """gn_stats=True: a Normalize() reads the result next -- where the kernel can, the conv's epilogue leaves the GroupNorm statistics
+        with the tensor (ops.conv3x3) and that layer skips its statistics pass."""
+        return ops.conv3x3(x, self.weight, self.bias, residual, self.mode, out_f32=out_f32, gn_stats=gn_stats)
 
 
 class Conv1x1(nn.Conv2d):
@@ -95,10 +97,12 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x, temb=None):
         h, x = self.norm1(x, swish=True, skip=True)
-        h = self.norm2(self.conv1(h), swish=True)
+        h = self.norm2(self.conv1(h, gn_stats=True), swish=True)
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
-        return self.conv2(h, residual=x)  # x + h in the conv epilogue
+        # x + h in the conv epilogue; what follows a ResnetBlock in Encoder / Decoder is a Normalize (of the next ResnetBlock, of an
+        # AttnBlock, or norm_out) except in front of a Down/Upsample, where the statistics are simply not read
+        return self.conv2(h, residual=x, gn_stats=True)
 
 
 class AttnBlock(nn.Module):

@@ -229,26 +229,47 @@ def _wino4_ok(h, w, cin, cout):
     return WINOGRAD and WINOGRAD4 and bool(_L().odvae_conv3x3_wino4_supported(h, w, cin, cout))
 
 
-def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False):
+# GroupNorm statistics of a conv's output from its own epilogue (conv3x3_wino4_f32.hip): the F(4x4) forward convs leave (sum, sum of
+# squares) per output tile and channel group, and the GroupNorm that reads the tensor skips its statistics pass.  ODVAE_GN_FUSED_STATS=0
+# turns it off.
+GN_FUSED_STATS = os.environ.get("ODVAE_GN_FUSED_STATS", "1") != "0"
+GN_GROUPS = 32      # Normalize() of the reference model: GroupNorm(32, C, eps 1e-6)
+
+
+def _gn_stats_ok(cout):
+    cpg = cout // GN_GROUPS
+    return GN_FUSED_STATS and cout % GN_GROUPS == 0 and 1 <= cpg <= 32 and (cpg & (cpg - 1)) == 0
+
+
+def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False, stats=False):
+    """stats=True (F(4x4) only): returns (y, partials [N][tiles][32][2]) -- the GroupNorm statistics of y per output tile."""
     L = _L()
     n, _, h, w = x.shape
     y = _new_cl(n, cout, h, w, x)
     tag = KERNEL_EVENTS.begin() if cout > 32 else None
-    fn = L.odvae_conv3x3_wino4_f32 if f4 else L.odvae_conv3x3_wino_f32
-    _lib.check(fn(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
-                  y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino4" if f4 else "conv3x3_wino")
+    partial = None
+    if stats:
+        partial = torch.empty(n, L.odvae_conv3x3_wino4_stats_chunks(h, w), GN_GROUPS, 2, dtype=torch.float32, device=x.device)
+        _lib.check(L.odvae_conv3x3_wino4_stats_f32(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                                                   y.data_ptr(), partial.data_ptr(), GN_GROUPS, _lib.stream_ptr()), "conv3x3_wino4_stats")
+    else:
+        fn = L.odvae_conv3x3_wino4_f32 if f4 else L.odvae_conv3x3_wino_f32
+        _lib.check(fn(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                      y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino4" if f4 else "conv3x3_wino")
     # issued multiply-adds per output pixel and (ci, co): F(2x2,3x3) 16 per 2x2 tile = 4, F(4x4,3x3) 36 per 4x4 tile = 2.25
     KERNEL_EVENTS.end("conv3x3_wino4" if f4 else "conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
                       4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
                       issued=2.0 * (2.25 if f4 else 4.0) * cin * cout * n * h * w)
-    return y
+    return (y, partial) if stats else y
 
 
 class _Conv3x3(Function):
     """mode 0: stride 1 pad 1; mode 1: Downsample (pad (0,1,0,1), stride 2); mode 2: Upsample (nearest 2x) + conv."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, mode, relu):
+    def forward(ctx, x, weight, bias, residual, mode, relu, gn_stats=False):
+        """gn_stats=True: returns (y, partials) when the F(4x4) kernel takes the layer (partials: GroupNorm statistics of y per output
+        tile, not differentiable), (y, None) otherwise."""
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
@@ -259,7 +280,10 @@ class _Conv3x3(Function):
             up = "wino4" if (not relu and _wino4_ok(x.shape[2], x.shape[3], cin, cout)) else "wino"
         fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), up)  # both packs in one launch
         b = bias.detach().contiguous() if bias is not None else None
-        if up in ("wino", "wino4"):
+        partial = None
+        if up == "wino4" and gn_stats and _gn_stats_ok(cout):
+            y, partial = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, f4=True, stats=True)
+        elif up in ("wino", "wino4"):
             y = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, act=1 if relu else 0, f4=up == "wino4")
         else:
             y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
@@ -268,10 +292,14 @@ class _Conv3x3(Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, weight, y if relu else None)
+        if gn_stats:
+            if partial is not None:
+                ctx.mark_non_differentiable(partial)
+            return y, partial
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         L = _L()
         x, weight, y_act = ctx.saved_tensors
         mode = ctx.mode
@@ -323,16 +351,24 @@ class _Conv3x3(Function):
                 KERNEL_EVENTS.end("conv3x3_wgrad", 2.0 * 9 * cin * cout * n * ho * wo, None,
                                   issued=_conv_issued(wmode, n, hi, wi, ho, wo, cin, cout))
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None
 
 
-def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=False):
+def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=False, gn_stats=False):
     """bf16 activations take the mixed-precision kernels (conv_bf16.hip); out_f32 makes that path hand back f32 (the f32 ends of
-    the network: encoder.conv_out -> moments, decoder.conv_out -> reconstruction)."""
+    the network: encoder.conv_out -> moments, decoder.conv_out -> reconstruction).
+    gn_stats=True: the caller says a GroupNorm(32) reads the result next.  Where the F(4x4) kernel takes the layer, its output transform
+    then also writes the GroupNorm statistics of y per tile; they travel as the attribute `_gn_partials` of the returned tensor (the
+    Python object, so a copy or a view does not carry them) and `group_norm` / `group_norm_skip` use them instead of a statistics pass."""
     if x.dtype == BF16:
         if relu:
             raise NotImplementedError("fused ReLU is only on the f32 path (the LPIPS-style VGG stack stays f32)")
         return _ConvB.apply(x, weight, bias, residual, mode, bool(out_f32))
+    if gn_stats and not relu and mode == 0:
+        y, partial = _Conv3x3.apply(x, weight, bias, residual, mode, relu, True)
+        if partial is not None:
+            y._gn_partials = partial
+        return y
     return _Conv3x3.apply(x, weight, bias, residual, mode, relu)
 
 
@@ -562,7 +598,9 @@ def attention_qkv(qkv):
 # ------------------------------------------------------------------------------------------------------
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False):
+    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False, partials=None):
+        """partials [N][chunks][groups][2]: the statistics of x as the conv that produced it left them (ops.conv3x3(gn_stats=True)):
+        no statistics pass."""
         L = _L()
         x = _cl(x)
         n, c, h, w = x.shape
@@ -571,11 +609,16 @@ class _GroupNorm(Function):
         y = _new_cl(n, c, h, w, x)
         mean = torch.empty(n, groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty(n, groups, dtype=torch.float32, device=x.device)
-        wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, groups), x)
         tag = KERNEL_EVENTS.begin(secondary=True)
-        _lib.check(L.odvae_groupnorm_fwd_f32(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps),
-                                             int(swish), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn,
-                                             _lib.stream_ptr()), "groupnorm_fwd")
+        if partials is not None and partials.shape[0] == n and partials.shape[2] == groups:
+            _lib.check(L.odvae_groupnorm_fwd_partials_f32(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps),
+                                                          int(swish), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                          partials.data_ptr(), int(partials.shape[1]), _lib.stream_ptr()), "groupnorm_fwd_partials")
+        else:
+            wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, groups), x)
+            _lib.check(L.odvae_groupnorm_fwd_f32(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps),
+                                                 int(swish), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn,
+                                                 _lib.stream_ptr()), "groupnorm_fwd")
         # algorithmic traffic: x read once, y written once
         KERNEL_EVENTS.end("groupnorm", 0.0, tag, 4.0 * 2 * n * h * w * c, issued=0.0)
         ctx.groups, ctx.swish = groups, int(swish)
@@ -608,13 +651,21 @@ class _GroupNorm(Function):
                    "groupnorm_bwd")
         # algorithmic traffic: x, dy (and the folded skip gradient) read once, dx written once
         KERNEL_EVENTS.end("groupnorm", 0.0, tag, 4.0 * (3 + (dskip is not None)) * n * h * w * c, issued=0.0)
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
+
+
+def _gn_partials_of(x, groups):
+    """Statistics the producing conv attached to this very tensor object (ops.conv3x3(gn_stats=True)), if they fit."""
+    p = getattr(x, "_gn_partials", None)
+    if p is None or not GN_FUSED_STATS or groups != GN_GROUPS or p.shape[0] != x.shape[0] or p.device != x.device:
+        return None
+    return p
 
 
 def group_norm(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     if x.dtype == BF16:
         return _GroupNormB.apply(x, gamma, beta, groups, eps, swish)
-    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish)
+    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, False, _gn_partials_of(x, groups))
 
 
 def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
@@ -623,7 +674,7 @@ def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     autograd's separate 3-pass add)."""
     if x.dtype == BF16:
         return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, True)
-    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True)
+    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True, _gn_partials_of(x, groups))
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -100,6 +100,13 @@ int odvae_conv3x3_wino4_supported(int H, int W, int Cin, int Cout);
 int odvae_conv3x3_pack_wino4_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
 int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
                             const float* bias, const float* residual, float* y, int act /* must be 0: no fused activation */, void* stream);
+/* The same, and the output transform also leaves the GroupNorm statistics of y for the layer that reads it (GroupNorm row:
+ * "statistics from the producing conv's epilogue"): gn_partial [N][odvae_conv3x3_wino4_stats_chunks(H, W)][gn_groups][2] = (sum, sum of
+ * squares) of y per output tile and channel group, every slot written by exactly one block (deterministic).  Cout / gn_groups must be a
+ * power of two <= 32.  Feed it to odvae_groupnorm_fwd_partials_f32. */
+int odvae_conv3x3_wino4_stats_chunks(int H, int W);
+int odvae_conv3x3_wino4_stats_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                                  const float* bias, const float* residual, float* y, float* gn_partial, int gn_groups, void* stream);
 
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
  * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)
@@ -126,6 +133,11 @@ size_t odvae_groupnorm_workspace_bytes(int N, int HW, int C, int G);
 int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
                             float eps, int swish, float* y, float* mean, float* rstd,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* the same without the statistics pass: partial [N][chunks][G][2] = (sum, sum of squares) of x per chunk and channel group, as the kernel
+ * that produced x left them (odvae_conv3x3_wino4_stats_f32); finalize (f64, fixed order) + apply, x read once */
+int odvae_groupnorm_fwd_partials_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                                     float eps, int swish, float* y, float* mean, float* rstd,
+                                     const float* partial, int chunks, void* stream);
 int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
                             float* dx, float* dgamma, float* dbeta, const float* dx_add,

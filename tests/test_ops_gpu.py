@@ -277,6 +277,48 @@ def test_winograd4_through_the_c_abi(hip_lib, n, cin, cout, h, w, res, bias):
     assert L.odvae_conv3x3_wino4_f32(xd.data_ptr(), n, h, w, cin, fwd.data_ptr(), cout, None, None, y.data_ptr(), 1, _lib.stream_ptr()) != 0   # no fused ReLU
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,res", [(2, 64, 128, 16, 32, False), (3, 128, 256, 36, 68, True), (1, 256, 512, 32, 32, True),
+                                                (2, 64, 64, 20, 36, False), (8, 128, 128, 128, 128, True)])
+def test_groupnorm_statistics_from_the_conv_epilogue(hip_lib, monkeypatch, n, cin, cout, h, w, res):
+    """SURVEY.md 2.1, GroupNorm row: the F(4x4) conv's output transform leaves (sum, sum of squares) of y per output tile and channel group
+    (4 / 8 / 16 / 2 channels per group; partial blocks; the persistent form; with / without a residual), and the GroupNorm that reads y runs
+    finalize + apply only.  Checked: the partials against sums of the tensor the conv wrote (f64 on the host), GroupNorm + swish through
+    the fused path against torch on the host and against the unfused HIP path, and the backward pass through both layers."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD4", True)
+    g = torch.Generator().manual_seed(n + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    r = torch.randn(n, cout, h, w, generator=g) if res else None
+    gamma, beta = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g).to(dev())
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "GN_FUSED_STATS", fused)
+        xd = x.to(dev()).requires_grad_(True)
+        wd = wt.to(dev()).requires_grad_(True)
+        gd, bd = gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
+        y = ops.conv3x3(xd, wd, b.to(dev()), r.to(dev()) if res else None, gn_stats=True)
+        part = getattr(y, "_gn_partials", None)
+        assert (part is not None) == fused
+        if fused:
+            assert part.shape == (n, hip_lib.odvae_conv3x3_wino4_stats_chunks(h, w), 32, 2)
+            yc = y.detach().double().cpu().reshape(n, 32, cout // 32, h * w)
+            want = torch.stack([yc.sum(dim=(2, 3)), (yc * yc).sum(dim=(2, 3))], dim=-1)          # [n][32][2]
+            got = part.double().cpu().sum(dim=1)
+            assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        z = ops.group_norm(y, gd, bd, 32, 1e-6, swish=True)
+        z.backward(gy)
+        outs.append((y.detach(), z.detach(), xd.grad, wd.grad, gd.grad, bd.grad))
+    ref_y = F.conv2d(x, wt, b, padding=1) + (r if res else 0.0)
+    ref_z = F.silu(F.group_norm(ref_y, 32, gamma, beta, eps=1e-6))
+    close(outs[0][1], ref_z, 5e-4, "conv -> GroupNorm(stats from the epilogue) + swish vs torch")
+    assert torch.equal(outs[0][0], outs[1][0])                      # the conv output itself does not depend on the switch
+    for a, c, what in zip(outs[0][1:], outs[1][1:], ("z", "dx", "dw", "dgamma", "dbeta")):
+        assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item(), what
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 128, 16, 16), (1, 128, 256, 8, 12), (3, 256, 128, 6, 10),
                                             (2, 128, 128, 2, 2), (1, 384, 128, 4, 34)])
 def test_winograd_domain_weight_gradient(hip_lib, n, cin, cout, h, w):
