@@ -633,7 +633,7 @@ class _GroupNorm(Function):
         L = _L()
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if dy is None:               # only the skip branch carried a gradient
-            return dskip, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None
         dy = _cl(dy)
         if dskip is not None:
             dskip = _cl(dskip)
