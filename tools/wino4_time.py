@@ -47,6 +47,16 @@ for (b, cin, cout, h) in ([(32, 128, 128, 256)] if os.environ.get("WINO_ONLY_BIG
             for _ in range(2 if os.environ.get("WINO_ONLY_BIG") else 60): y = ops.conv3x3(x, w, bias)
             e1.record(); torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / 60)
+    ops.WINOGRAD4 = True
+    with torch.no_grad():       # the same with the GroupNorm statistics of y written by the output transform
+        for _ in range(4 if os.environ.get("WINO_ONLY_BIG") else 40): y = ops.conv3x3(x, w, bias, gn_stats=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2 if os.environ.get("WINO_ONLY_BIG") else 60): y = ops.conv3x3(x, w, bias, gn_stats=True)
+        e1.record(); torch.cuda.synchronize()
+    t_stats = e0.elapsed_time(e1) / (2 if os.environ.get("WINO_ONLY_BIG") else 60)
     fl = 2.0 * 9 * cin * cout * b * h * h
     print("B%d %d->%d @%d: F(2x2) %.3f ms  F(4x4) %.3f ms  (x%.2f; %.0f / %.0f direct-form TFLOP/s; F(4x4) executes %.3f of the f32 MFMA peak)"
           % (b, cin, cout, h, out[0], out[1], out[0] / out[1], fl / out[0] / 1e9, fl / out[1] / 1e9, fl / 4 / out[1] / 1e9 / 157.3), flush=True)
+    print("      with GroupNorm statistics in the output transform: %.3f ms (+%.1f %%)" % (t_stats, 100 * (t_stats / out[1] - 1)), flush=True)
