@@ -112,20 +112,125 @@ def host_enqueue_ms(step, first_index, reps=3):
     return best
 
 
-def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False):
+def _amdgpu_sysfs(dev):
+    """sysfs directory of the amdgpu card behind torch device `dev` (matched by PCI address), or None."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        want = None
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    for c in cards:
+        try:
+            if want and os.path.basename(os.path.realpath(c)).startswith(want):
+                return c
+        except OSError:
+            pass
+    return cards[0] if len(cards) == 1 else None
+
+
+def gpu_state(dev):
+    """Shader / memory clock, power draw and cap, temperature as the kernel driver reports them right now (sysfs; no GPU call, so
+    it is safe between timed regions).  Missing files are skipped: the record says what the box let an ordinary user read."""
+    import glob
+    out = {}
+    base = _amdgpu_sysfs(dev)
+    if base is None:
+        return {"error": "no amdgpu sysfs entry matched the device"}
+
+    def rd(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+    for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+        txt = rd(os.path.join(base, fn))
+        if txt:
+            cur = [l for l in txt.splitlines() if l.rstrip().endswith("*")]
+            out[key + "_mhz_current"] = cur[0].split(":")[1].replace("*", "").strip() if cur else None
+            out[key + "_levels"] = [l.split(":")[1].replace("*", "").strip() for l in txt.splitlines() if ":" in l]
+    for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+        for key, fn, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("power_cap_w", "power1_cap", 1e-6),
+                               ("sclk_hwmon_mhz", "freq1_input", 1e-6), ("mclk_hwmon_mhz", "freq2_input", 1e-6),
+                               ("temp_edge_c", "temp1_input", 1e-3), ("temp_junction_c", "temp2_input", 1e-3), ("temp_mem_c", "temp3_input", 1e-3)):
+            v = rd(os.path.join(hw, fn))
+            if v is not None and key not in out:
+                try:
+                    out[key] = float(v) * scale
+                except ValueError:
+                    pass
+    v = rd(os.path.join(base, "gpu_busy_percent"))
+    if v is not None:
+        out["gpu_busy_percent"] = v
+    return out
+
+
+_ALLOC_KEYS = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms", "num_sync_all_streams")
+
+
+def alloc_counters(dev):
+    st = torch.cuda.memory_stats(dev)
+    d = {k: int(st.get(k, 0)) for k in _ALLOC_KEYS}
+    d["reserved_gb"] = st.get("reserved_bytes.all.current", 0) / 1e9
+    d["allocated_gb"] = st.get("allocated_bytes.all.current", 0) / 1e9
+    return d
+
+
+def timed_loop(step, first_index, steps, dev):
+    """K steps with one HIP event in front of each and one behind the last, on the stream the kernels are launched on: wall time
+    (host clock, device-synchronised at both ends), the GPU-side elapsed time of the same loop, per-step GPU times, the host's enqueue
+    time, the caching allocator's device-call counters over the loop (a hipMalloc / hipFree inside it is a device synchronisation)
+    and the clocks / power the driver reports before and after."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    state0, a0 = gpu_state(dev), alloc_counters(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i].record()
+        step(first_index + i)
+    ev[steps].record()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    state1, a1 = gpu_state(dev), alloc_counters(dev)
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    diag = {"gpu_elapsed_ms_per_step": ev[0].elapsed_time(ev[steps]) / steps,
+            "gpu_step_ms": {"min": per[0], "median": per[len(per) // 2], "max": per[-1],
+                            "all": [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(steps)] if steps <= 64 else None},
+            "allocator_delta": {k: a1[k] - a0[k] for k in _ALLOC_KEYS},
+            "allocator_after": {"reserved_gb": a1["reserved_gb"], "allocated_gb": a1["allocated_gb"]},
+            "gpu_state_before": state0, "gpu_state_after": state1}
+    return wall, host, diag
+
+
+def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False, force_dist=False):
     """A second, smaller measurement in the same process (one GPU): images/s of another BASELINE.json configuration, no kernel
-    events.  Returns the dict that goes under `other_configs` of the one JSON line, or the error text -- it never fails the
-    headline."""
+    events.  The caching allocator is emptied first, so a run never starts inside what the previous one left reserved.  Returns the
+    dict that goes under `other_configs` of the one JSON line, or the error text -- it never fails the headline.
+    force_dist: the data-parallel path on one GPU -- an RCCL group of world size 1, the bucketed GradReducer and the pre-scaled loss."""
+    import gc
     from odvae_amd import synthetic
     from odvae_amd.trainer import Trainer
+    model = trainer = None
     try:
+        gc.collect()
+        torch.cuda.empty_cache()
         torch.manual_seed(23)
         lat = res // 16
         gkw = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if gan else {}
         model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gkw).to(dev).train()
         model.decoder.activation_checkpoint = bool(ckpt)
         model._global_step = 1
-        trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if gan else (0,), precision=precision)
+        group = None
+        if force_dist:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29541")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            group = dist.group.WORLD
+        trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0, 1) if gan else (0,), precision=precision, process_group=group)
         data = synthetic.make_batch(batch, res, seed=23)
         data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
 
@@ -137,23 +242,25 @@ def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False):
             step(i)
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i)
-        host = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, host, diag = timed_loop(step, warmup, steps, dev)
         host1 = host_enqueue_ms(step, warmup + steps)
-        return {"value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-                "host_enqueue_ms_per_step": host1, "host_over_gpu": host1 / (dt / steps * 1e3), "host_loop_ms_per_step": host / steps * 1e3,
-                "dtype": "bf16" if str(precision) == "bf16" else "f32", "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
-                "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, z=%dx%dx16, B=%d/GPU, %s%s, %s"
-                           % (res, res, lat, lat, batch,
-                              "PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if gan else "rec+KL only",
-                              ", activation-checkpointed Decoder" if ckpt else "",
-                              "bf16 mixed precision" if str(precision) == "bf16" else "fp32")}}
+        out = {"value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+               "host_enqueue_ms_per_step": host1, "host_over_gpu": host1 / (dt / steps * 1e3), "host_loop_ms_per_step": host / steps * 1e3,
+               "dtype": "bf16" if str(precision) == "bf16" else "f32", "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+               "backend": "rccl (world size 1, bucketed GradReducer)" if force_dist else "none",
+               "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, z=%dx%dx16, B=%d/GPU, %s%s, %s"
+                          % (res, res, lat, lat, batch,
+                             "PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if gan else "rec+KL only",
+                             ", activation-checkpointed Decoder" if ckpt else "",
+                             "bf16 mixed precision" if str(precision) == "bf16" else "fp32")}}
+        out.update(diag)
+        return out
     except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
         return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        del model, trainer
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def launch_ranks(args):
@@ -297,15 +404,20 @@ def main():
         # (200 vs 251 images/s).  In bf16 mode one launch in eight of the dominant family is bracketed (17 per step).
         ops.KERNEL_EVENTS.sample = 8 if args.bf16 else 1
     sample = 8 if (args.bf16 and not args.no_kernel_events) else 1   # launches / share below are scaled back by it (estimates when > 1)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one per step boundary, on the launch stream
+    state0, alloc0 = gpu_state(dev), alloc_counters(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        step_ev[i].record()
         step(args.warmup + i)
+    step_ev[args.steps].record()
     host_s = time.perf_counter() - t0      # the host has enqueued every launch of the timed steps; the GPU is still working
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    state1, alloc1 = gpu_state(dev), alloc_counters(dev)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -347,6 +459,13 @@ def main():
             # is the enqueue time inside the timed loop, back-pressure of the launch queue included (it reads ~ms_per_step by itself).
             "host_enqueue_ms_per_step": host1_ms, "host_over_gpu": (host1_ms / (elapsed / args.steps * 1e3)) if host1_ms else None,
             "host_loop_ms_per_step": host_s / args.steps * 1e3,
+            # GPU-side view of the same timed loop (rank 0): one HIP event per step boundary on the launch stream
+            "gpu_elapsed_ms_per_step": step_ev[0].elapsed_time(step_ev[args.steps]) / args.steps,
+            "gpu_step_ms": (lambda per: {"min": min(per), "median": sorted(per)[len(per) // 2], "max": max(per),
+                                         "all": [round(v, 3) for v in per] if len(per) <= 64 else None})(
+                [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]),
+            "allocator_delta": {k: alloc1[k] - alloc0[k] for k in _ALLOC_KEYS},
+            "gpu_state_before": state0, "gpu_state_after": state1,
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
                        % (args.res, args.res, args.batch,
                           ("PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
@@ -358,8 +477,8 @@ def main():
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
             tfile = None
-            for cand in (("r03_bf16_conv_traffic.json", "r02_bf16_conv_traffic.json") if args.bf16
-                         else ("r03_conv3x3_traffic.json", "r02_conv3x3_traffic.json", "r01_conv3x3_traffic.json")):
+            for cand in (("r04_bf16_conv_traffic.json", "r03_bf16_conv_traffic.json") if args.bf16
+                         else ("r04_conv3x3_traffic.json", "r03_conv3x3_traffic.json")):
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     tfile = cand
                     break
@@ -416,13 +535,14 @@ def main():
                               "frac": r["tbytes_per_s"] * 1e3 / PEAK_HBM_GBS,
                               "algorithmic_bytes_per_step": r["bytes_per_launch"] * r["launches"],
                               "note": "algorithmic bytes = x read + y written (forward), x, dy (, skip gradient) read + dx written (backward)"})
-                    fam = os.path.join(ROOT, "profiles", "r02_family_traffic.json")
+                    # this round's PMC passes only: a file from before a kernel change is not evidence for these kernels
+                    fam = os.path.join(ROOT, "profiles", "r04_family_traffic.json")
                     if not (args.gan or args.bf16 or args.ckpt_decoder) and args.res == 256 and args.batch == 32 and os.path.exists(fam):
                         # HBM bytes the family actually moves (statistics / reduce are passes of their own), from the committed PMC
                         # passes of this command (FETCH_SIZE x2 + WRITE_SIZE, two steps counted), over the time measured live here
                         ks = json.load(open(fam))["kernels"]
                         moved = sum((v["fetch_bytes_total_corrected"] + v["write_bytes_total"]) / 2.0 for k, v in ks.items() if k.startswith("gn_"))
-                        e.update({"traffic": moved, "traffic_unit": "HBM bytes per step (PMC, profiles/r02_family_traffic.json)",
+                        e.update({"traffic": moved, "traffic_unit": "HBM bytes per step (PMC, profiles/r04_family_traffic.json)",
                                   "achieved_on_traffic": moved / (e["total_ms"] * 1e-3) / 1e9,
                                   "frac_on_traffic": moved / (e["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS})
                 else:
@@ -440,11 +560,22 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            out["other_configs"] = {
-                "configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder": side_run(dev, 512, 32, 4, 2, True, "bf16"),
-                "configs[1] shape (256x256, B=32) in bf16 mixed precision": side_run(dev, 256, 32, 15, 5, False, "bf16"),
-                "configs[3] 256x256 B=32 fp32, PatchGAN discriminator + LPIPS-style loss, both optimizers": side_run(dev, 256, 32, 4, 2, False, 32, gan=True),
-            }
+            # order: the bf16 run at the headline shape goes FIRST (fresh allocator, nothing bf16 has run yet) and is repeated LAST,
+            # after the 512x512 run and the GAN run, so the record itself shows whether its rate depends on what ran before it
+            oc = {}
+            oc["configs[1] shape (256x256, B=32) in bf16 mixed precision"] = side_run(dev, 256, 32, 15, 5, False, "bf16")
+            oc["configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder"] = side_run(dev, 512, 32, 4, 2, True, "bf16")
+            oc["configs[3] 256x256 B=32 fp32, PatchGAN discriminator + LPIPS-style loss, both optimizers"] = side_run(dev, 256, 32, 4, 2, False, 32, gan=True)
+            oc["configs[1] shape in bf16, repeated after the 512x512 and GAN runs"] = side_run(dev, 256, 32, 15, 5, False, "bf16")
+            oc["configs[1] (256x256, B=32, fp32) through the data-parallel path: RCCL world size 1, bucketed reducer"] = \
+                side_run(dev, 256, 32, 6, 2, False, 32, force_dist=True)
+            out["other_configs"] = oc
+            try:
+                import torch.distributed as dist
+                if dist.is_initialized() and not use_dist:
+                    dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
             print("[bench] side runs done", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             # one warm-up step, then >= 3 timed steps (B=2 at 256x256: ~4.5 s each on 16 cores)

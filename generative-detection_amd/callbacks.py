@@ -24,6 +24,9 @@ class Callback:
     def on_validation_batch_end(self, trainer, pl_module, outputs, batch, batch_idx, dataloader_idx=0):
         pass
 
+    def on_validation_end(self, trainer, pl_module):
+        pass
+
 
 def make_grid(tensor, nrow=8, padding=2, pad_value=0.0):
     """torchvision.utils.make_grid for a [B, C, H, W] batch (normalize=False): a single image is returned as it is; otherwise the
@@ -112,7 +115,8 @@ class ImageLogger(Callback):
                 if self.clamp:
                     images[k] = torch.clamp(images[k], -1., 1.)
         written = []
-        logger = getattr(pl_module, "logger", None)
+        # (`_odvae_logger`: where trainer.Trainer(logger=) parks it when `logger` is the read-only property of a real LightningModule)
+        logger = getattr(pl_module, "logger", None) or getattr(pl_module, "_odvae_logger", None)
         if not self.disable_local_logging and _is_rank_zero():
             save_dir = getattr(logger, "save_dir", None) or "."
             written = self.log_local(save_dir, split, images, pl_module.global_step, getattr(pl_module, "current_epoch", 0), batch_idx)
@@ -139,6 +143,92 @@ class ImageLogger(Callback):
     def on_validation_batch_end(self, trainer, pl_module, outputs, batch, batch_idx, dataloader_idx=0):
         if not self.disabled and pl_module.global_step > 0:
             self.log_img(pl_module, batch, batch_idx, split="val")
+
+
+class ModelCheckpoint(Callback):
+    """The part of pytorch_lightning.callbacks.ModelCheckpoint the reference configures (train.py:228-249): `dirpath`,
+    `filename="{epoch:06}"`, `save_last=True`, `save_weights_only=True`, and -- when the model names a `monitor` (yaml:5,
+    `val/rec_loss`) -- `monitor` with `save_top_k=3`, mode "min".  Runs at the end of every validation pass
+    (`Trainer.validate` / the epoch end of `Trainer.fit`): writes `<dirpath>/<filename>.ckpt` through `trainer.save_checkpoint` when
+    the monitored epoch mean is among the k best so far (and removes the file that dropped out), then `last.ckpt`.  [PL-1.9] naming:
+    `{epoch:06}` becomes `epoch=000003` (metric names are inserted), a clash gets a `-v1` suffix."""
+
+    def __init__(self, dirpath=None, filename=None, monitor=None, verbose=False, save_last=None, save_top_k=1, save_weights_only=False,
+                 mode="min", **_ignored):
+        super().__init__()
+        if mode not in ("min", "max"):
+            raise ValueError("ModelCheckpoint mode %r" % (mode,))
+        self.dirpath, self.filename, self.monitor, self.verbose = dirpath, filename, monitor, verbose
+        self.save_last, self.save_top_k, self.save_weights_only, self.mode = save_last, save_top_k, save_weights_only, mode
+        self.best_k_models, self.kth_best_model_path = {}, ""
+        self.best_model_path, self.best_model_score, self.last_model_path = "", None, ""
+
+    @property
+    def state_key(self):
+        return "ModelCheckpoint{'monitor': %r, 'mode': %r}" % (self.monitor, self.mode)
+
+    def state_dict(self):
+        return {"monitor": self.monitor, "best_model_score": self.best_model_score, "best_model_path": self.best_model_path,
+                "best_k_models": dict(self.best_k_models), "kth_best_model_path": self.kth_best_model_path,
+                "last_model_path": self.last_model_path, "dirpath": self.dirpath}
+
+    def format_checkpoint_name(self, metrics):
+        import re
+        name = self.filename or "{epoch}-{step}"
+        for group in re.findall(r"(\{.*?)[:\}]", name):
+            key = group[1:]
+            name = name.replace(group, key + "={" + key.replace("/", "_"), 1)       # auto_insert_metric_name
+        vals = {k.replace("/", "_"): (v.item() if torch.is_tensor(v) else v) for k, v in metrics.items()}
+        return name.format(**vals)
+
+    def _path(self, trainer, metrics):
+        base = self.format_checkpoint_name(metrics)
+        path, v = os.path.join(self.dirpath or ".", base + ".ckpt"), 0
+        while os.path.exists(path) and path not in self.best_k_models:
+            v += 1
+            path = os.path.join(self.dirpath or ".", "%s-v%d.ckpt" % (base, v))
+        return path
+
+    def on_validation_end(self, trainer, pl_module):
+        metrics = dict(trainer.callback_metrics)
+        metrics.update(epoch=trainer.current_epoch, step=pl_module.global_step)
+        sign = 1.0 if self.mode == "min" else -1.0
+        if self.monitor is None:
+            if self.save_top_k != 0:
+                path = self._path(trainer, metrics)
+                trainer.save_checkpoint(path, weights_only=self.save_weights_only)
+                if self.save_top_k == 1 and self.best_model_path and self.best_model_path != path and _is_rank_zero() and os.path.exists(self.best_model_path):
+                    os.remove(self.best_model_path)     # without a monitor PL keeps the latest only (top_k = 1)
+                self.best_model_path = path
+        elif self.save_top_k != 0:
+            if self.monitor not in metrics:
+                raise KeyError("ModelCheckpoint(monitor=%r): validation logged %s" % (self.monitor, sorted(trainer.callback_metrics)))
+            score = float(metrics[self.monitor])
+            full = self.save_top_k > 0 and len(self.best_k_models) >= self.save_top_k
+            worst = max(self.best_k_models, key=lambda k: sign * self.best_k_models[k]) if self.best_k_models else None
+            if not full or sign * score < sign * self.best_k_models[worst]:
+                path = self._path(trainer, metrics)
+                trainer.save_checkpoint(path, weights_only=self.save_weights_only)
+                if full:
+                    del self.best_k_models[worst]
+                    if _is_rank_zero() and os.path.exists(worst):
+                        os.remove(worst)
+                self.best_k_models[path] = score
+                self.kth_best_model_path = max(self.best_k_models, key=lambda k: sign * self.best_k_models[k])
+                self.best_model_path = min(self.best_k_models, key=lambda k: sign * self.best_k_models[k])
+                self.best_model_score = self.best_k_models[self.best_model_path]
+                if self.verbose:
+                    logging.info("ModelCheckpoint: %s = %.6f -> %s", self.monitor, score, path)
+        if self.save_last:
+            self.last_model_path = trainer.save_checkpoint(os.path.join(self.dirpath or ".", "last.ckpt"), weights_only=self.save_weights_only)
+
+
+def default_modelcheckpoint(model, ckptdir):
+    """What train.py:228-241 builds when the yaml has no `modelcheckpoint` section."""
+    kw = dict(dirpath=ckptdir, filename="{epoch:06}", verbose=True, save_last=True, save_weights_only=True)
+    if hasattr(model, "monitor"):
+        kw.update(monitor=model.monitor, save_top_k=3)
+    return ModelCheckpoint(**kw)
 
 
 def _is_rank_zero():

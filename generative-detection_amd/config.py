@@ -17,7 +17,16 @@ def get_obj_from_str(string, reload=False):
     module, cls = string.rsplit(".", 1)
     if reload:
         importlib.reload(importlib.import_module(module))
-    return getattr(importlib.import_module(module, package=None), cls)
+    try:
+        return getattr(importlib.import_module(module, package=None), cls)
+    except ModuleNotFoundError:
+        # train.py:229 targets `pytorch_lightning.callbacks.ModelCheckpoint`; where pytorch_lightning is absent (this image) the
+        # callbacks of that name built for trainer.Trainer stand in -- only for that one package prefix, everything else still raises
+        if module == "pytorch_lightning.callbacks":
+            from . import callbacks
+            if hasattr(callbacks, cls):
+                return getattr(callbacks, cls)
+        raise
 
 
 def instantiate_from_config(config):

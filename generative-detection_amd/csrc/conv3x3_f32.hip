@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(ConvParams p) {
   const int segs = p.Wo / 32;                 // host guarantees Wo % 32 == 0
   const int ntiles = p.N * p.Ho * segs;
   const bool relu = p.act != 0;
-  for (int tile = wave_in_grid; tile < ntiles; tile += nwaves) {
+  for (int tile = __builtin_amdgcn_readfirstlane(wave_in_grid); tile < ntiles; tile += nwaves) {
     const int seg = tile % segs, row = tile / segs;       // row = n * Ho + y
     const int y = row % p.Ho, x0 = seg * 32;
     float a[16];
@@ -609,13 +609,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(ConvParams p) {
       a[s] = ok ? v : 0.f;
     }
     f32x16 acc[4];
+    // the tile's 32 pixels x Cout channels are one contiguous run of y: a buffer descriptor over exactly that run (base wave-uniform),
+    // ONE per-lane offset (row 4 (lane >> 5), channel c0 + li), the accumulator row as a scalar offset and the channel tile as an
+    // immediate -- sixty-four 64-bit store addresses, loop-invariant and therefore hoisted and spilled (33 registers), are gone
     const int64_t obase = ((int64_t)row * p.Wo + x0) * p.Cout;
+    const int run = 32 * p.Cout * 4, rstep = p.Cout * 4;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + obase, 0, run, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : p.y) + obase, 0,
+                                                                         p.residual ? run : 0, 0x00020000);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      const int co = c0 + ct * 32 + li;
+      const unsigned vo = (c0 + ct * 32 + li < p.Cout) ? (unsigned)((4 * kk * p.Cout + c0 + ct * 32 + li) * 4) : 0x7FFFFFF0u;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        acc[ct][r] = bv[ct] + ((p.residual && co < p.Cout) ? p.residual[obase + (int64_t)acc_row(r, lane) * p.Cout + co] : 0.f);
+        acc[ct][r] = bv[ct] + (p.residual ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, vo, ((r & 3) + 8 * (r >> 2)) * rstep, 0)) : 0.f);
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s)
@@ -623,13 +630,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(ConvParams p) {
       for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(a[s], bw[ct][s], acc[ct]);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      const int co = c0 + ct * 32 + li;
-      if (co < p.Cout) {
+      const unsigned vo = (c0 + ct * 32 + li < p.Cout) ? (unsigned)((4 * kk * p.Cout + c0 + ct * 32 + li) * 4) : 0x7FFFFFF0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[ct][r];
-          p.y[obase + (int64_t)acc_row(r, lane) * p.Cout + co] = relu ? fmaxf(v, 0.f) : v;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[ct][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(relu ? fmaxf(v, 0.f) : v), yrs, vo, ((r & 3) + 8 * (r >> 2)) * rstep, 0);
       }
     }
   }

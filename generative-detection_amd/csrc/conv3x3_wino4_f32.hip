@@ -40,6 +40,7 @@ constexpr int HALO_DMA_PER_WAVE = 3;       // 24 LDS-DMA instructions of 1 KB pe
 constexpr unsigned HALO_B = 8 * HALO_DMA_PER_WAVE * 1024;   // 24 576
 constexpr unsigned V_B = 36 * 1024;        // [36 xi][2 quads][32 tiles][4 floats]
 constexpr unsigned LDS_B = 2 * HALO_B + 2 * V_B;            // 122 880
+constexpr unsigned STATS_B = 4 * 512 * 8;                  // STATS build: (sum, sum of squares) per output-transform pass and thread, 16 KB behind the V stages
 constexpr unsigned OOB = 0x7FFFFFF0u;
 
 struct Wino4Params {
@@ -78,6 +79,10 @@ __device__ __forceinline__ void column_pass_store(const f32x2 (&t)[6], unsigned 
   lds_st64f(dst + 5 * 1024, 4.f * t[1] + (t[5] - 5.f * t[3]));
 }
 
+// STATS: the output transform also leaves the GroupNorm statistics of y (p.gn_partial).  A template parameter, not a run-time branch: the
+// two accumulators and the exchange live only in the instantiation the statistics launches use, so the data-gradient launches and every
+// launch without a GroupNorm consumer run the plain build (255 registers, no scratch).
+template <bool STATS>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float dsmem[];
   const unsigned lds0 = lds_addr_of(dsmem);
@@ -112,9 +117,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   unsigned hvoff[HALO_DMA_PER_WAVE];
   auto set_halo = [&](const Tile& T) {
     xrs = rsrc_words(p.x + (int64_t)T.n * p.H * p.W * p.Cin, (unsigned)(p.H * p.W * p.Cin) * 4u);
+    // (the slot -> (plane, row, x) arithmetic depends on the lane only; from an opaque copy of the lane id it is redone per tile --
+    // a dozen integer operations -- instead of being hoisted out of the tile loop and parked in scratch across the main loop)
+    int lane_h = lane;
+    asm volatile("" : "+v"(lane_h));
 #pragma unroll
     for (int k = 0; k < HALO_DMA_PER_WAVE; ++k) {
-      const int s = (wave + 8 * k) * 64 + lane;
+      const int s = (wave + 8 * k) * 64 + lane_h;
       const int quad = s >= PLANE ? 1 : 0;
       const int rem = s - quad * PLANE;
       const int hr = rem / ROWP, xp = rem - hr * ROWP;
@@ -292,7 +301,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   const int cstep = p.Cout * 4, rstep = p.W * p.Cout * 4;
   const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane_e) * 4);
   const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane_e) * 4);
-  float gsum = 0.f, gsq = 0.f;      // GroupNorm statistics of this thread's outputs (p.gn_partial)
 #pragma unroll
   for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
@@ -315,6 +323,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
           seed[a][c] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, base, a * rstep + c * cstep, 0));
     }
     if (!(ODVAE_W4_ABL & 512)) __syncthreads();
+    float psum = 0.f, psq = 0.f;      // STATS: this pass's share of the GroupNorm statistics; parked in LDS at the end of the pass, so
+                                      // that nothing of it stays in a register across the passes (with two accumulators live over
+                                      // the whole output transform hipcc spilled nine registers into scratch)
     float tt[6][4];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -339,10 +350,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       for (int a = 0; a < 4; ++a)
         if (!(ODVAE_W4_ABL & 128) || yv[a] == 12345.678f)
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
-      if (p.gn_partial && base != OOB) {      // (a 4x4 tile is inside the image as a whole: H and W are multiples of 4)
+      if (STATS && base != OOB) {      // (a 4x4 tile is inside the image as a whole: H and W are multiples of 4)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { gsum += yv[a]; gsq += yv[a] * yv[a]; }
+        for (int a = 0; a < 4; ++a) { psum += yv[a]; psq += yv[a] * yv[a]; }
       }
+    }
+    if (STATS) {
+      lds_st32f(lds0 + LDS_B + (unsigned)((rq * 512 + tid) * 8), psum);
+      lds_st32f(lds0 + LDS_B + (unsigned)((rq * 512 + tid) * 8 + 4), psq);
     }
     // the next tile's halo: with a residual the 16 loads + 16 stores of pass 0 are younger than it, without one the 32 stores of passes 0, 1
     if (has_next && rq == (p.residual ? 0 : 1)) wait_vm_but<32>();
@@ -350,8 +365,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   }
   // ---- GroupNorm statistics of this tile for the layer that reads y: (sum, sum of squares) per channel group, one slot per
   // (image, tile, group) written by exactly one block -- the consumer's finalize kernel adds the tiles up in f64, in fixed order ----
-  if (p.gn_partial) {
+  if (STATS) {
     const int cpg = p.gn_cpg;
+    float gsum = 0.f, gsq = 0.f;      // this thread's four passes, in pass order (each thread reads back what it wrote itself)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      gsum += lds_ld32f(lds0 + LDS_B + (unsigned)((rq * 512 + tid) * 8));
+      gsq += lds_ld32f(lds0 + LDS_B + (unsigned)((rq * 512 + tid) * 8 + 4));
+    }
     gsum += __shfl_xor(gsum, 32, 64); gsq += __shfl_xor(gsq, 32, 64);          // the two tile columns of a lane pair
     for (int o = 1; o < cpg; o <<= 1) { gsum += __shfl_xor(gsum, o, 64); gsq += __shfl_xor(gsq, o, 64); }   // the channels of a group
     __syncthreads();                 // the last pass's reads of X are done: its first 2 KB become the exchange area S[e2][ct2][32][2]
@@ -360,8 +381,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       lds_st32f(X0 + (unsigned)((((wave >> 1) * 2 + ct2) * 32 + li_e) * 8 + 4), gsq);
     }
     __syncthreads();
-    if (tid < 64 && (tid & (cpg - 1)) == 0) {       // thread = (co tile tid >> 5, first lane of a group)
-      const int ctq = tid >> 5, l = tid & 31, cg = n0 + ctq * 32 + l;
+    int tid_e = tid;                 // (opaque, as lane_e above: the exchange addresses are made here, not parked in scratch across the main loop)
+    asm volatile("" : "+v"(tid_e));
+    if (tid_e < 64 && (tid_e & (cpg - 1)) == 0) {       // thread = (co tile tid >> 5, first lane of a group)
+      const int ctq = tid_e >> 5, l = tid_e & 31, cg = n0 + ctq * 32 + l;
       if (cg < p.Cout) {
         float a = 0.f, b = 0.f;
 #pragma unroll
@@ -516,7 +539,9 @@ static int wino4_launch(const float* x, int N, int H, int W, int Cin, const floa
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino4: too many tiles");
   static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
   p.xcd = xcd ? 1 : 0;
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_B);
+  const auto kern = gn_partial ? conv3x3_wino4_kernel<true> : conv3x3_wino4_kernel<false>;
+  const unsigned lds_bytes = gn_partial ? LDS_B + STATS_B : LDS_B;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) {
     odvae_set_error("conv3x3_wino4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     return ODVAE_ERR_HIP;
@@ -530,8 +555,8 @@ static int wino4_launch(const float* x, int N, int H, int W, int Cin, const floa
   }();
   const int ny = p.CoutP / BN;
   p.persist = (!no_persist && cus % (8 * ny) == 0 && sp >= 2 * (cus / ny)) ? 1 : 0;
-  if (p.persist) hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3(cus), dim3(512), LDS_B, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)sp, ny), dim3(512), LDS_B, static_cast<hipStream_t>(stream), p);
+  if (p.persist) hipLaunchKernelGGL(kern, dim3(cus), dim3(512), lds_bytes, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)sp, ny), dim3(512), lds_bytes, static_cast<hipStream_t>(stream), p);
   ODVAE_LAUNCH_CHECK("conv3x3_wino4");
   return ODVAE_OK;
 }

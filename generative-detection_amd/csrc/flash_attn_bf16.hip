@@ -1129,11 +1129,30 @@ template <int D> constexpr int fwd_pair_lds() { return PairGeom<D>::NSTAGE_PC * 
 template <int D> constexpr int dkv_pair_lds() { return 4 * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
 template <int D> constexpr int dq_pair_lds() { return PairGeom<D>::NSTAGE_PC * PairGeom<D>::STAGEB + 2 * 4 * 2048; }
 
+thread_local hipError_t g_flash_attr_error = hipSuccess;
+thread_local int g_flash_attr_lds = 0;
 template <typename K>
 void launch_dyn(K kernel, dim3 grid, int lds_bytes, hipStream_t st, const FlashP& p, int threads = 256) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  // a refused LDS size (the pair kernels ask for up to ~148 KB) must not surface as an anonymous launch failure, or not at all:
+  // the error text names the size, and the launch is skipped so that ODVAE_LAUNCH_CHECK reports this call, not a later one
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) {
+    g_flash_attr_error = e;
+    g_flash_attr_lds = lds_bytes;
+    return;
+  }
   hipLaunchKernelGGL(kernel, grid, dim3(threads), lds_bytes, st, p);
 }
+#define ODVAE_FLASH_LAUNCH_CHECK(name)                                                                                   \
+  do {                                                                                                                 \
+    if (g_flash_attr_error != hipSuccess) {                                                                            \
+      odvae_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d bytes) failed: %s", name, g_flash_attr_lds, \
+                      hipGetErrorString(g_flash_attr_error));                                                          \
+      g_flash_attr_error = hipSuccess;                                                                                 \
+      return ODVAE_ERR_HIP;                                                                                            \
+    }                                                                                                                  \
+    ODVAE_LAUNCH_CHECK(name);                                                                                          \
+  } while (0)
 // ODVAE_FLASH_BWD_V1=1 keeps the first-generation kernels (one 32-row problem per wave; forward and backward) for in-process A/B runs
 bool flash_bwd_v1() {
   static const bool v = [] { const char* e = getenv("ODVAE_FLASH_BWD_V1"); return e && e[0] == '1'; }();
@@ -1174,7 +1193,7 @@ int odvae_flash_attn_fwd_bf16(const void* qkv, int N, int T, int C, float scale,
   if (!flash_bwd_v1() && (C == 128 || C == 256) && (int64_t)qb * N < 0x7FFFFFFF) {
     if (C == 256) launch_dyn(flash_fwd_pair_kernel<256>, dim3(qb * N), fwd_pair_lds<256>(), st, p, 512);
     else launch_dyn(flash_fwd_pair_kernel<128>, dim3(qb * N), fwd_pair_lds<128>(), st, p, 512);
-    ODVAE_LAUNCH_CHECK("flash_attn_fwd (pair kernel)");
+    ODVAE_FLASH_LAUNCH_CHECK("flash_attn_fwd (pair kernel)");
     return ODVAE_OK;
   }
   switch (C) {
@@ -1183,7 +1202,7 @@ int odvae_flash_attn_fwd_bf16(const void* qkv, int N, int T, int C, float scale,
     case 256: launch_dyn(flash_fwd_kernel<256, 256, 32>, dim3(qb, N, 1), fwd_lds(256, 256, 32), st, p); break;
     default:  launch_dyn(flash_fwd_kernel<512, 128, 32>, dim3(qb, N, 4), fwd_lds(512, 128, 32), st, p); break;
   }
-  ODVAE_LAUNCH_CHECK("flash_attn_fwd");
+  ODVAE_FLASH_LAUNCH_CHECK("flash_attn_fwd");
   return ODVAE_OK;
 }
 
@@ -1210,7 +1229,7 @@ int odvae_flash_attn_bwd_bf16(const void* qkv, const void* o, const void* d_o, c
       launch_dyn(flash_dq_pair_kernel<128>, dim3(qb * N), dq_pair_lds<128>(), st, p, 512);
       launch_dyn(flash_dkv_pair_kernel<128>, dim3(qb * N), dkv_pair_lds<128>(), st, p, 512);
     }
-    ODVAE_LAUNCH_CHECK("flash_attn_bwd (pair kernels)");
+    ODVAE_FLASH_LAUNCH_CHECK("flash_attn_bwd (pair kernels)");
     return ODVAE_OK;
   }
   switch (C) {
@@ -1227,7 +1246,7 @@ int odvae_flash_attn_bwd_bf16(const void* qkv, const void* o, const void* d_o, c
       launch_dyn(flash_dq_kernel<512, 128, 32>, dim3(qb, N, 4), dq_lds(512, 32), st, p);
       launch_dyn(flash_dkv_kernel<512, 64, 32>, dim3(qb, N, 8), dkv_lds(512, 32), st, p); break;
   }
-  ODVAE_LAUNCH_CHECK("flash_attn_bwd");
+  ODVAE_FLASH_LAUNCH_CHECK("flash_attn_bwd");
   return ODVAE_OK;
 }
 

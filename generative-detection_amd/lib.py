@@ -13,6 +13,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "odvae_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
+ABI_VERSION = 2   # == ODVAE_ABI_VERSION in include/odvae_hip.h; bumped whenever the exported surface changes
+
 # name -> (restype, argtypes); mirrors include/odvae_hip.h one to one (tests/test_abi.py checks that)
 PROTOTYPES = {
     "odvae_last_error": (_c.c_char_p, []),
@@ -136,6 +138,15 @@ def load():
             "HIP kernel library %s not found; run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the OD-VAE hot path." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    # the version first: a stale prebuilt library then fails here, with a message that says so, not at some symbol lookup
+    try:
+        lib.odvae_abi_version.restype = _I
+        have = lib.odvae_abi_version()
+    except AttributeError as e:
+        raise HipLibraryError("%s does not export odvae_abi_version (not an OD-VAE kernel library?)" % LIB_PATH) from e
+    if have != ABI_VERSION:
+        raise HipLibraryError("ABI version mismatch: library %d, binding %d (stale libodvae_hip.so? rebuild with __graft_entry__.build())"
+                              % (have, ABI_VERSION))
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)
@@ -143,8 +154,9 @@ def load():
             raise HipLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.odvae_abi_version() != 1:
-        raise HipLibraryError("ABI version mismatch: library %d, binding 1" % lib.odvae_abi_version())
+    if lib.odvae_abi_version() != ABI_VERSION:
+        raise HipLibraryError("ABI version mismatch: library %d, binding %d (stale libodvae_hip.so? rebuild with __graft_entry__.build())"
+                              % (lib.odvae_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -83,6 +83,9 @@ class ResnetBlock(nn.Module):
         if temb_channels > 0:
             raise NotImplementedError("timestep embedding is not part of the autoencoder path (temb_ch = 0)")
         self.in_channels, self.out_channels = in_channels, out_channels
+        # whether a Normalize() reads this block's output (the next ResnetBlock's norm1, an AttnBlock's norm, norm_out): conv2 then
+        # leaves the GroupNorm statistics with its result.  Encoder / Decoder clear it on the blocks in front of a Down / Upsample.
+        self.gn_stats_out = True
         self.use_conv_shortcut = conv_shortcut
         self.norm1 = Normalize(in_channels)
         self.conv1 = Conv3x3(in_channels, out_channels)
@@ -100,9 +103,8 @@ class ResnetBlock(nn.Module):
         h = self.norm2(self.conv1(h, gn_stats=True), swish=True)
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x)
-        # x + h in the conv epilogue; what follows a ResnetBlock in Encoder / Decoder is a Normalize (of the next ResnetBlock, of an
-        # AttnBlock, or norm_out) except in front of a Down/Upsample, where the statistics are simply not read
-        return self.conv2(h, residual=x, gn_stats=True)
+        # x + h in the conv epilogue
+        return self.conv2(h, residual=x, gn_stats=self.gn_stats_out)
 
 
 class AttnBlock(nn.Module):
@@ -164,6 +166,8 @@ class Encoder(nn.Module):
                     stage.attn.append(make_attn(block_in, attn_type))
             if level != self.num_resolutions - 1:
                 stage.downsample = Downsample(block_in, resamp_with_conv)
+                if len(stage.attn) == 0:
+                    stage.block[-1].gn_stats_out = False      # its output feeds the Downsample conv, not a Normalize
                 curr_res //= 2
             self.down.append(stage)
         self.mid = nn.Module()
@@ -227,6 +231,8 @@ class Decoder(nn.Module):
                     stage.attn.append(make_attn(block_in, attn_type))
             if level != 0:
                 stage.upsample = Upsample(block_in, resamp_with_conv)
+                if len(stage.attn) == 0:
+                    stage.block[-1].gn_stats_out = False      # its output feeds the Upsample conv, not a Normalize
                 curr_res *= 2
             stages.insert(0, stage)  # index == resolution level, as upstream
         self.up = nn.ModuleList(stages)

@@ -367,7 +367,9 @@ def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=Fal
     if gn_stats and not relu and mode == 0:
         y, partial = _Conv3x3.apply(x, weight, bias, residual, mode, relu, True)
         if partial is not None:
-            y._gn_partials = partial
+            # the statistics are valid for exactly these values: the tag (storage, version counter, shape) lets the consumer tell
+            # whether anything wrote to the tensor in between (an in-place op, a hook, a checkpoint wrapper's copy)
+            y._gn_partials = (partial, y.data_ptr(), y._version, tuple(y.shape))
         return y
     return _Conv3x3.apply(x, weight, bias, residual, mode, relu)
 
@@ -656,8 +658,14 @@ class _GroupNorm(Function):
 
 def _gn_partials_of(x, groups):
     """Statistics the producing conv attached to this very tensor object (ops.conv3x3(gn_stats=True)), if they fit."""
-    p = getattr(x, "_gn_partials", None)
-    if p is None or not GN_FUSED_STATS or groups != GN_GROUPS or p.shape[0] != x.shape[0] or p.device != x.device:
+    tagged = getattr(x, "_gn_partials", None)
+    if tagged is None or not GN_FUSED_STATS or groups != GN_GROUPS:
+        return None
+    p, ptr, version, shape = tagged
+    if ptr != x.data_ptr() or version != x._version or shape != tuple(x.shape) or p.device != x.device:
+        return None      # the tensor was written to (or is not the conv's output any more): take the statistics pass
+    n, _, h, w = x.shape
+    if p.shape[0] != n or p.shape[2] != groups or p.shape[1] != _L().odvae_conv3x3_wino4_stats_chunks(h, w):
         return None
     return p
 

@@ -25,6 +25,7 @@
 extern "C" {
 #endif
 
+#define ODVAE_ABI_VERSION 2            /* odvae_abi_version() of a library built from this header */
 #define ODVAE_OK 0
 #define ODVAE_ERR_ARG 1
 #define ODVAE_ERR_WORKSPACE 2
@@ -32,7 +33,7 @@ extern "C" {
 
 /* ---- runtime.cpp ------------------------------------------------------------------------------- */
 const char* odvae_last_error(void);   /* host string, thread-local */
-int odvae_abi_version(void);          /* == 1 for this header */
+int odvae_abi_version(void);          /* == ODVAE_ABI_VERSION of this header; bumped whenever the exported surface changes */
 const char* odvae_target_arch(void);  /* "gfx950" */
 
 /* ---- gemm_f32.hip: torch.nn.Conv2d(k=1) / torch.bmm ---------------------------------------------

@@ -1,1 +1,1 @@
-from odvae_amd.callbacks import Callback, DeviceStatsMonitor, ImageLogger, TQDMProgressBar, make_grid  # noqa: F401
+from odvae_amd.callbacks import Callback, DeviceStatsMonitor, ImageLogger, ModelCheckpoint, TQDMProgressBar, make_grid  # noqa: F401

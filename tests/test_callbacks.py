@@ -79,3 +79,75 @@ def test_yaml_callbacks_resolve():
     il = cbs["image_logger"]
     assert type(il).__name__ == "ImageLogger" and il.batch_freq == 1000 and il.max_images == 1
     assert il.log_steps == [2 ** n for n in range(10)]
+
+
+class _TinyVal(torch.nn.Module):
+    """A LightningModule-shaped toy: one optimizer, a validation_step that logs a scripted `val/rec_loss`."""
+
+    def __new__(cls, *a, **k):
+        from odvae_amd.lightning import LightningModule
+
+        class Impl(LightningModule):
+            def __init__(self, scores):
+                super().__init__()
+                self.lin = torch.nn.Linear(4, 4)
+                self.learning_rate = 1e-2
+                self.monitor = "val/rec_loss"
+                self.scores = list(scores)
+
+            def training_step(self, batch, batch_idx, optimizer_idx):
+                return self.lin(batch).pow(2).mean()
+
+            def validation_step(self, batch, batch_idx):
+                s = self.scores[0]
+                self.log("val/rec_loss", torch.tensor(s + 0.1 * batch_idx), sync_dist=True)
+                self.log("val/other", 1.0)
+                return None
+
+            def configure_optimizers(self):
+                return [torch.optim.Adam(self.lin.parameters(), lr=self.learning_rate, betas=(0.5, 0.9))], []
+        return Impl(*a, **k)
+
+
+def test_modelcheckpoint_keeps_the_three_best_and_last(tmp_path):
+    """train.py:228-249: filename {epoch:06}, save_last, save_weights_only, monitor = model.monitor, save_top_k 3 (mode min).  Five
+    epochs with scripted validation means 0.55, 0.35, 0.75, 0.25, 0.65 (two batches each: s, s + 0.1): the files on disk are always the
+    three best epochs + last.ckpt, a worse epoch writes only last.ckpt, `epoch` / `global_step` in the files follow the loop."""
+    from odvae_amd.callbacks import default_modelcheckpoint
+    from odvae_amd.config import Config, instantiate_from_config
+    from odvae_amd.trainer import Trainer
+    scores = [0.5, 0.3, 0.7, 0.2, 0.6]
+    model = _TinyVal(scores)
+    ckdir = os.path.join(tmp_path, "checkpoints")
+    cb = default_modelcheckpoint(model, ckdir)
+    assert cb.monitor == "val/rec_loss" and cb.save_top_k == 3 and cb.save_last and cb.save_weights_only
+    trainer = Trainer(model, optimizer_indices=(0,), callbacks=[cb])
+    train = [torch.randn(2, 4) for _ in range(3)]
+    val = [torch.randn(2, 4) for _ in range(2)]
+    seen = []
+    for epoch in range(5):
+        trainer.fit(train, val_batches=val, max_epochs=1)
+        model.scores.pop(0)
+        seen.append(sorted(os.listdir(ckdir)))
+        assert abs(float(trainer.callback_metrics["val/rec_loss"]) - (scores[epoch] + 0.05)) < 1e-6     # the epoch MEAN over two batches
+        last = torch.load(os.path.join(ckdir, "last.ckpt"))
+        assert last["epoch"] == epoch and last["global_step"] == 3 * (epoch + 1) and "optimizer_states" not in last
+    assert seen[0] == ["epoch=000000.ckpt", "last.ckpt"]
+    assert seen[2] == ["epoch=000000.ckpt", "epoch=000001.ckpt", "epoch=000002.ckpt", "last.ckpt"]
+    assert seen[3] == ["epoch=000000.ckpt", "epoch=000001.ckpt", "epoch=000003.ckpt", "last.ckpt"]      # 0.75 dropped out
+    assert seen[4] == seen[3]                                                                           # 0.65 is not among the best three
+    assert cb.best_model_path.endswith("epoch=000003.ckpt") and abs(cb.best_model_score - 0.25) < 1e-6
+    assert cb.kth_best_model_path.endswith("epoch=000000.ckpt")
+    # the same callback through the reference's own config route (target: pytorch_lightning.callbacks.ModelCheckpoint, train.py:229)
+    cfg = Config({"target": "pytorch_lightning.callbacks.ModelCheckpoint",
+                  "params": {"dirpath": ckdir, "filename": "{epoch:06}", "verbose": True, "save_last": True, "save_weights_only": True}})
+    assert type(instantiate_from_config(cfg)).__name__ == "ModelCheckpoint"
+    # full checkpoint + resume: weights, optimizer moments, counters
+    path = trainer.save_checkpoint(os.path.join(tmp_path, "full.ckpt"))
+    model2 = _TinyVal(scores)
+    trainer2 = Trainer(model2, optimizer_indices=(0,))
+    trainer2.load_checkpoint(path)
+    assert model2.global_step == 15 and trainer2.current_epoch == 5
+    assert torch.equal(model2.lin.weight, model.lin.weight)
+    s1, s2 = trainer.optimizers[0].state_dict()["state"], trainer2.optimizers[0].state_dict()["state"]
+    assert all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) and float(s1[k]["step"]) == float(s2[k]["step"]) == 15.0 for k in s1)

@@ -300,7 +300,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(hip_lib, monkeypatch, n, ci
         wd = wt.to(dev()).requires_grad_(True)
         gd, bd = gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
         y = ops.conv3x3(xd, wd, b.to(dev()), r.to(dev()) if res else None, gn_stats=True)
-        part = getattr(y, "_gn_partials", None)
+        part = ops._gn_partials_of(y, 32)
         assert (part is not None) == fused
         if fused:
             assert part.shape == (n, hip_lib.odvae_conv3x3_wino4_stats_chunks(h, w), 32, 2)
@@ -317,6 +317,28 @@ def test_groupnorm_statistics_from_the_conv_epilogue(hip_lib, monkeypatch, n, ci
     assert torch.equal(outs[0][0], outs[1][0])                      # the conv output itself does not depend on the switch
     for a, c, what in zip(outs[0][1:], outs[1][1:], ("z", "dx", "dw", "dgamma", "dbeta")):
         assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item(), what
+
+
+def test_epilogue_statistics_are_dropped_when_the_tensor_was_written_to(hip_lib, monkeypatch):
+    """The statistics ride on the conv's output tensor OBJECT, tagged with its storage pointer, version counter and shape.  An in-place
+    write between the conv and the GroupNorm (a hook, a future fusion) changes the version: the GroupNorm must then take its own
+    statistics pass and still normalise the values the tensor holds NOW."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD4", True)
+    monkeypatch.setattr(ops, "GN_FUSED_STATS", True)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 16, 32, generator=g).to(dev())
+    wt = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(dev())
+    gamma, beta = torch.randn(64, generator=g).to(dev()), torch.randn(64, generator=g).to(dev())
+    y = ops.conv3x3(x, wt, None, None, gn_stats=True)
+    assert ops._gn_partials_of(y, 32) is not None
+    assert ops._gn_partials_of(y, 16) is None                     # another group count: not these statistics
+    assert ops._gn_partials_of(y.clone(), 32) is None             # a copy is another object
+    y.mul_(3.0).add_(1.0)                                         # in-place: same object, same storage, new version
+    assert ops._gn_partials_of(y, 32) is None
+    z = ops.group_norm(y, gamma, beta, 32, 1e-6, swish=True)
+    ref = F.silu(F.group_norm(y.detach().cpu().contiguous(), 32, gamma.cpu(), beta.cpu(), eps=1e-6))
+    close(z, ref, 5e-4, "GroupNorm after an in-place write (stale epilogue statistics must not be used)")
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 128, 16, 16), (1, 128, 256, 8, 12), (3, 256, 128, 6, 10),

@@ -106,7 +106,20 @@ def _worker(rank, world, port, out_dir):
     net3(full_x[shard]).pow(2).mean().backward()
     red3.finish()
     g3 = torch.cat([p.grad.reshape(-1) for p in net3.parameters()]).clone()
-    torch.save({"g3": g3, "sd3": net3.state_dict(), "nb3": len(red3.buckets), "order3": list(red3.launch_order), "synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
+    # the same through the Trainer: comm_dtype=torch.bfloat16 is an opt-in (the default keeps f32 buckets, whatever the precision)
+    assert all(r.comm_dtype is None for r in trainer.reducers)
+    torch.manual_seed(300 + rank)
+    model4 = TinyLightning()
+    trainer4 = Trainer(model4, gradient_clip_val=1.0, optimizer_indices=(0, 1), bucket_mb=0.02, comm_dtype=torch.bfloat16)
+    red4 = trainer4.reducers[0]
+    assert red4.comm_dtype == torch.bfloat16
+    loss4 = model4.training_step((full_x[shard], full_y[shard]), 0, 0)
+    red4.prepare_for_backward()
+    (loss4 * red4.inv_world).backward()
+    red4.finish()
+    grads4 = {n: p.grad.clone() for n, p in model4.gen.named_parameters()}
+    sd4 = {k: v.clone() for k, v in model4.state_dict().items()}
+    torch.save({"grads4": grads4, "sd4": sd4, "g3": g3, "sd3": net3.state_dict(), "nb3": len(red3.buckets), "order3": list(red3.launch_order), "synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
                 "global_step": model._global_step}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -128,6 +141,15 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     for n, p in ref.gen.named_parameters():
         assert torch.allclose(r0["grads"][n], p.grad, atol=1e-6), n
         assert torch.equal(r0["grads"][n], r1["grads"][n]), n
+    # Trainer with bf16 buckets (opt-in): averaged gradient = full-batch gradient up to the bf16 rounding of each rank's pre-scaled
+    # share (2^-9 relative per addend; stated bound 2^-7 of each tensor's largest entry), identical on both ranks
+    ref4 = TinyLightning()
+    ref4.load_state_dict(r0["sd4"])
+    ref4.training_step((full_x, full_y), 0, 0).backward()
+    for n, p in ref4.gen.named_parameters():
+        assert torch.equal(r0["grads4"][n], r1["grads4"][n]), n
+        assert (r0["grads4"][n] - p.grad).abs().max() <= 2.0 ** -7 * p.grad.abs().max() + 1e-12, n
+        assert not torch.equal(r0["grads4"][n], p.grad) or p.grad.abs().max() == 0, n     # (it did travel as bf16)
     # buckets fire during backward, last layers first (reverse arena order), and every bucket fired
     assert r0["order"] == r1["order"] and len(r0["order"]) == r0["nbuckets"]
     assert r0["order"][0] == r0["nbuckets"] - 1 and r0["order"][-1] == 0
