@@ -325,6 +325,24 @@ int odvae_groupnorm_fwd_bf16(const void* x, int N, int HW, int C, int G, const f
   return ODVAE_OK;
 }
 
+// The same without the statistics pass: partial [N][chunks][G][2] = (sum, sum of squares) of x per chunk and channel group as the conv
+// that produced x left them (odvae_conv_bf16_stats: one chunk per output tile).  finalize (f64, fixed order over the chunks) + apply.
+int odvae_groupnorm_fwd_partials_bf16(const void* x, int N, int HW, int C, int G, const float* gamma, const float* beta, float eps, int swish,
+                                      void* y, float* mean, float* rstd, const float* partial, int chunks, void* stream) {
+  GnB s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_fwd_partials_bf16: unsupported shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && gamma && beta && y && mean && rstd && partial && chunks > 0, "groupnorm_fwd_partials_bf16: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)partial & 7) == 0, "groupnorm_fwd_partials_bf16: misaligned operand");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GnB sf = s;
+  sf.chunks = chunks;
+  hipLaunchKernelGGL(gn_finalize_kernel<GnB>, dim3(ceil_div(N * G, 4)), dim3(256), 0, st, partial, sf, eps, mean, rstd);
+  hipLaunchKernelGGL(gnb_apply_kernel, dim3(apply_blocks(s), N), dim3(256), 0, st, static_cast<const bf16_t*>(x), s, gamma, beta, mean, rstd,
+                     swish, static_cast<bf16_t*>(y));
+  ODVAE_LAUNCH_CHECK("groupnorm_fwd_partials_bf16");
+  return ODVAE_OK;
+}
+
 // dx bf16 (+ dx_add bf16, the folded skip gradient, or NULL), dgamma / dbeta f32 [C]
 int odvae_groupnorm_bwd_bf16(const void* x, const void* dy, int N, int HW, int C, int G, const float* gamma, const float* beta,
                              const float* mean, const float* rstd, int swish, void* dx, float* dgamma, float* dbeta, const void* dx_add,

@@ -31,6 +31,8 @@ struct ConvB {
   int N, Hi, Wi, Cin, Ho, Wo, Cout, CinP, CoutP;
   int tiles_x, tiles_y, out_f32;
   int xcd;                 // 1: XCD-contiguous tile order
+  float* gn_partial;       // STATS launches: [N][tiles per image][gn_groups][2] = (sum, sum of squares) of y per tile and channel group
+  int gn_groups, gn_cpg;   // channel groups of the GroupNorm that reads y; channels per group (a multiple of 4, <= 128)
 };
 
 template <int MODE, int TH> struct HaloB;
@@ -59,9 +61,13 @@ __device__ __forceinline__ void halo_origin_b(int oy0, int ox0, int& iy0, int& i
 }
 
 // WCT x WPT MFMA tiles per wave (channel tiles x pixel tiles), WAVES_CO x WAVES_PX waves; WAVES_PX * WPT pixel tiles of 32 = the
-// TH x 16 block tile.  The wide form (TH = 16: 64 co x 128 px per wave) halves the weight-fragment traffic per MFMA: with 2 x 2
-// tiles every MFMA needs 512 B of weights through the vector L1 (64 B/clk per CU) -- as many cycles as the MFMAs themselves.
-template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX, int TH, int MINW = 1>
+// TH x 16 block tile (TH = 8 in every instantiation that is launched).
+// STATS (stride-1 3x3, bf16 output): the epilogue also leaves the GroupNorm statistics of y -- of the ROUNDED bf16 values, the ones the
+// GroupNorm reads -- per output tile and channel group: a lane owns a pixel and 4-channel runs, so a run's sums are a 32-lane
+// butterfly, the two pixel halves of the block meet in LDS, and one thread per group writes its slot (no atomics; the consumer's
+// finalize adds the tiles in f64 in a fixed order).  A template parameter: data-gradient launches and convs without a GroupNorm
+// behind them run the plain build.
+template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX, int TH, int MINW = 1, bool STATS = false>
 __global__ __launch_bounds__(256, MINW) void conv_bf16_kernel(ConvB p) {
   static_assert(WAVES_CO * WAVES_PX == 4 && WAVES_PX * WPT * 32 == TH * TW, "tile layout");
   constexpr int BCO = WAVES_CO * WCT * 32;
@@ -217,6 +223,11 @@ __global__ __launch_bounds__(256, MINW) void conv_bf16_kernel(ConvB p) {
   }
 
   // ---- epilogue: stores only ------------------------------------------------------------------------------------------------
+  float gs[WCT][4], gq[WCT][4];      // STATS: this lane's sums per (channel tile, 8-channel step) = per 4-channel run
+#pragma unroll
+  for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { gs[ct][g] = 0.f; gq[ct][g] = 0.f; }
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
       static_cast<char*>(p.y) + (int64_t)n * p.Ho * p.Wo * p.Cout * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
 #pragma unroll
@@ -238,557 +249,51 @@ __global__ __launch_bounds__(256, MINW) void conv_bf16_kernel(ConvB p) {
           v.x = pack_bf16x2(acc[ct][pt][4 * g + 0], acc[ct][pt][4 * g + 1]);
           v.y = pack_bf16x2(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
+          if (STATS && off != OOB) {
+            const float r0 = bf16_lo(v.x), r1 = bf16_hi(v.x), r2 = bf16_lo(v.y), r3 = bf16_hi(v.y);
+            gs[ct][g] += (r0 + r1) + (r2 + r3);
+            gq[ct][g] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          }
         }
       }
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Wide tile for the stride-1 3x3 convs with more than 64 output channels (every ResnetBlock conv and its data gradient):
-// block = 16 x 16 output pixels x 128 output channels, 4 waves of 64 co x 128 px (2 x 4 MFMA tiles).
-//
-// Why.  In conv_bf16_kernel's 128-pixel tile every MFMA needs 512 B of weights through the vector L1 (64 B/clk per CU): as many
-// cycles as the MFMAs themselves.  Here one 16-byte weight load feeds four MFMAs (256 B per MFMA).  The first attempt at this tile
-// (64-channel chunks, halo staged through registers: 424 registers, 93 KB of LDS, ONE 4-wave block per CU) ran at 0.56x the narrow
-// tile.  This form fits two blocks per CU: __launch_bounds__(256, 2) keeps it inside the 256 architectural registers (VGPR-form
-// MFMAs, no accumulator-file copies), the halo takes no registers at all -- it arrives by LDS-DMA (asm, bf16_common.h) into a ring of
-// three 21 KB stages, 32 channels per chunk, two chunks ahead, ONE barrier per chunk -- and the LDS image is unpadded [halo px][32 ch]
-// with the 16-byte chunk index XOR-swizzled by (px >> 2) & 3, so that sixteen consecutive pixels read by one ds_read_b128 lane group
-// fall on sixteen different chunk positions (the swizzle is applied to the DMA's per-lane source address and to every read).
-// ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv_bf16_wide_kernel(ConvB p) {
-  constexpr int KC = 32, KS = 2, TAPS = 9, NIT = TAPS * KS, TH = 16;
-  constexpr int HW = TW + 2, HPIX = (TH + 2) * HW;              // 18 x 18 halo pixels
-  constexpr int PIECES = (HPIX * 4 + 63) / 64;                  // 21 LDS-DMA wave-instructions (1 KiB) per stage
-  constexpr unsigned STAGEB = PIECES * 1024, NSTG = 3;
-  constexpr int WCT = 2, WPT = 4;
-  extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
-  const unsigned lds0 = lds_addr_of(smem);
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave >> 1, wpx = wave & 1;
-
-  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int co0 = blockIdx.y * 128;
-  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-  const int esz = p.out_f32 ? 4 : 2;
-  const unsigned OOB = 0x7FFFFFF0u;
-
-  // ---- halo fetch plan: piece j = wave + 4 k; lane fills 16-byte slot 64 j + lane = (halo pixel hp, chunk position chp) ----------
-  const i32x4_t xw = rsrc_words(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin, (unsigned)(p.Hi * p.Wi * p.Cin * 2));
-  constexpr int NPW = (PIECES + 3) / 4;                           // pieces per wave (6; the last round only has piece 20)
-  unsigned hvoff[NPW];
-#pragma unroll
-  for (int k = 0; k < NPW; ++k) {
-    const int slot = 64 * (wave + 4 * k) + lane;
-    const int hp = slot >> 2, chp = slot & 3;
-    const int ch = chp ^ ((hp >> 2) & 3);
-    const int iy = iy0 + hp / HW, ix = ix0 + hp % HW;
-    const bool ok = hp < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-    hvoff[k] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * ch) * 2) : OOB;
-  }
-  auto issue = [&](int chunk, unsigned stage) {
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-      const int j = wave + 4 * k;
-      if (j < PIECES)      // wave-uniform
-        lds_dma16(xw, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + stage + 1024u * j)), hvoff[k] + (unsigned)(chunk * KC * 2));
-    }
-  };
-  const int nchunks = p.CinP / KC;
-  issue(0, 0);
-  if (nchunks > 1) issue(1, STAGEB);
-
-  // this lane's pixel in each of its four pixel tiles (column of the MFMA result)
-  unsigned pixoff[WPT];
-  int hp0[WPT];
-#pragma unroll
-  for (int pt = 0; pt < WPT; ++pt) {
-    const int pm = (wpx * WPT + pt) * 32 + li;
-    const int pr = pm / TW, pc = pm % TW;
-    const int oy = oy0 + pr, ox = ox0 + pc;
-    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
-    hp0[pt] = pr * HW + pc;
-  }
-
-  // accumulators start at bias + residual: the epilogue is stores only
-  f32x16 acc[WCT][WPT];
-  {
-    const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
+  if (STATS) {
+    static_assert(!STATS || (WAVES_CO * WCT == 4 && WAVES_PX == 2), "statistics epilogue: 128 channels x two pixel halves per block");
+    float* red = reinterpret_cast<float*>(smem);      // [wpx][run 0..31][2]; the main loop ended on a barrier, the halo stages are dead
 #pragma unroll
     for (int ct = 0; ct < WCT; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
-        float bv[4];
+        float a = gs[ct][g], b = gq[ct][g];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
-#pragma unroll
-        for (int pt = 0; pt < WPT; ++pt) {
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.residual) {
-            const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
-            rv[0] = bf16_lo(v.x); rv[1] = bf16_hi(v.x); rv[2] = bf16_lo(v.y); rv[3] = bf16_hi(v.y);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ct][pt][4 * g + j] = bv[j] + rv[j];
+        for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }     // the 32 pixels of the lane group (h fixed)
+        if (li == 0) {
+          const int run = (wco * WCT + ct) * 8 + 2 * g + h;      // channels co0 + 4 run .. + 3
+          red[(wpx * 32 + run) * 2 + 0] = a;
+          red[(wpx * 32 + run) * 2 + 1] = b;
         }
       }
-  }
-
-  // ---- operand fetch -------------------------------------------------------------------------------------------------------
-  const int KT = p.CinP / 16, CT = p.CoutP / 32;
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.wpk), 0, TAPS * KT * CT * 1024, 0x00020000);
-  const int ct0 = co0 / 32 + wco * WCT;
-  const unsigned lane16 = lane * 16;
-  auto load_a = [&](int ch, int it, bf16x8 (&a)[WCT]) {   // step `it` of chunk `ch`; it >= NIT runs into chunk ch + 1 (or past the pack: zeros)
-    const int c2 = ch + it / NIT, i2 = it % NIT;
-    const int tap = i2 / KS, ks = i2 % KS;
-    const unsigned base = (unsigned)(((tap * KT + c2 * KS + ks) * CT + ct0) * 1024) + lane16;
-#pragma unroll
-    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(wrsrc, base + ct * 1024, 0, 0));
-  };
-  // pixel fragment of step (tap, ks): lane (pixel, h) reads chunk 2 ks + h of halo pixel hp = hp0 + kh * 18 + kw, stored at chunk
-  // position (2 ks + h) ^ ((hp >> 2) & 3)
-  auto load_b = [&](unsigned stage_addr, int it, bf16x8 (&b)[WPT]) {
-    const int tap = it / KS, ks = it % KS;
-    const int toff = (tap / 3) * HW + (tap % 3);
-#pragma unroll
-    for (int pt = 0; pt < WPT; ++pt) {
-      const unsigned hp = (unsigned)(hp0[pt] + toff);
-      const unsigned pos = ((hp >> 2) ^ (unsigned)(2 * ks + h)) & 3u;
-      b[pt] = frag_from_u32x4(lds_ld128(stage_addr + hp * 64u + pos * 16u));
-    }
-  };
-
-  constexpr int RA = 3, PA = RA - 1;
-  static_assert(NIT % RA == 0, "weight ring");
-  bf16x8 abuf[RA][WCT], bbuf[2][WPT];
-#pragma unroll
-  for (int j = 0; j < PA; ++j) load_a(0, j, abuf[j]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  unsigned cur = 0, nxt = STAGEB, fre = 2 * STAGEB;
-  for (int ch = 0; ch < nchunks; ++ch) {
-#ifndef ODVAE_CONVW_ABL_NODMA
-    if (ch + 2 < nchunks) issue(ch + 2, fre);          // the stage chunk ch - 1 left: its last reads ended before the barrier above
-#endif
-    const unsigned sa = lds0 + cur;
-    load_b(sa, 0, bbuf[0]);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      load_a(ch, it + PA, abuf[(it + PA) % RA]);
-      if (it + 1 < NIT) load_b(sa, it + 1, bbuf[(it + 1) % 2]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ct = 0; ct < WCT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(abuf[it % RA][ct], bbuf[it % 2][pt], acc[ct][pt]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    { const unsigned o = cur; cur = nxt; nxt = fre; fre = o; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
-
-  // ---- epilogue: stores only ------------------------------------------------------------------------------------------------
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      static_cast<char*>(p.y) + (int64_t)n * p.Ho * p.Wo * p.Cout * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
+    const int rpg = p.gn_cpg / 4;                     // 4-channel runs per group
+    if (tid < 32 / rpg) {                             // thread = group of this block's 128 channels
+      const int grp = co0 / p.gn_cpg + tid;
+      if (grp < p.gn_groups) {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < rpg; ++j)
 #pragma unroll
-  for (int ct = 0; ct < WCT; ++ct)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
-#pragma unroll
-      for (int pt = 0; pt < WPT; ++pt) {
-        if (p.out_f32) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ct][pt][4 * g + j]), yrsrc, off, 0, 0);
-          }
-        } else {
-          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
-          u32x2 v;
-          v.x = pack_bf16x2(acc[ct][pt][4 * g + 0], acc[ct][pt][4 * g + 1]);
-          v.y = pack_bf16x2(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
-        }
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// All operands through LDS (stride-1 3x3 convs with more than 64 output channels): block = 16 x 16 output pixels x 128 output
-// channels, 8 waves of 64 co x 64 px (2 x 2 MFMA tiles), 16 input channels per chunk.
-//
-// The lesson of the wide tile above: a wave's vector-memory operations complete in issue order, so a per-step weight load issued
-// behind the fetch of a later halo chunk waits out that fetch's HBM latency.  Here NO global load is waited for inside a chunk: the
-// chunk's weights (nine taps x four 32-channel tiles = 36 fragments of 1 KiB, which sit lane-linear in the pack exactly as an
-// LDS-DMA piece writes them) and its halo (18 x 18 pixels x 16 channels = 11 pieces) arrive by asm LDS-DMA in a ring of three 47 KB
-// stages, two chunks ahead; every MFMA operand is a ds_read_b128; one `s_waitcnt vmcnt(0)` + barrier per chunk (36 MFMAs per wave).
-// Halo image: [halo px][2 x 16 B], the half index XOR-ed with (px >> 3) & 1 so that sixteen consecutive pixels of a lane group cover
-// sixteen different 16-byte positions.
-// ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void conv_bf16_lds_kernel(ConvB p) {
-  constexpr int TAPS = 9, TH = 16, HW = TW + 2, HPIX = (TH + 2) * HW;
-  constexpr int WPIECES = TAPS * 4, HPIECES = (HPIX * 2 + 63) / 64, PIECES = WPIECES + HPIECES + 1;   // 36 + 11 + one dummy: six per wave
-  constexpr unsigned STAGEB = PIECES * 1024, HALO_OFF = WPIECES * 1024;
-  constexpr int WCT = 2, WPT = 2;
-  extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
-  const unsigned lds0 = lds_addr_of(smem);
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave >> 2, wpx = wave & 3;
-
-  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int co0 = blockIdx.y * 128;
-  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-  const int esz = p.out_f32 ? 4 : 2;
-  const unsigned OOB = 0x7FFFFFF0u;
-  const int KT = p.CinP / 16, CT = p.CoutP / 32;
-  const int nchunks = KT;
-
-  // ---- fetch plan: piece j = wave + 8 k (k = 0 .. 5); j < 36: weight fragment (tap j / 4, channel tile j % 4), else halo piece j - 36 --
-  const i32x4_t xw = rsrc_words(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin, (unsigned)(p.Hi * p.Wi * p.Cin * 2));
-  const i32x4_t ww = rsrc_words(p.wpk, (unsigned)(TAPS * KT * CT * 1024));
-  unsigned hvoff[2];                 // this lane's source offsets of the wave's (up to) two halo pieces, chunk 0
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int j = wave + 8 * (4 + q);
-    const int slot = 64 * (j - WPIECES) + lane;
-    const int px = slot >> 1, half = (slot & 1) ^ ((px >> 3) & 1);
-    const int iy = iy0 + px / HW, ix = ix0 + px % HW;
-    const bool ok = j >= WPIECES && px < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;   // piece 47 is all out of range: zeros
-    hvoff[q] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * half) * 2) : OOB;
-  }
-  const unsigned lane16 = lane * 16;
-  auto issue = [&](int kt, unsigned stage) {
-    const unsigned st = lds0 + stage;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int j = wave + 8 * k;                     // wave-uniform
-      if (j < WPIECES) {
-        const int tap = j >> 2, ct = j & 3;
-        lds_dma16(ww, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + 1024u * j)),
-                  (unsigned)(((tap * KT + kt) * CT + co0 / 32 + ct) * 1024) + lane16);
-      } else {      // (the last piece only pads every wave's batch to six pieces: the counted wait below needs one number)
-        lds_dma16(xw, (unsigned)__builtin_amdgcn_readfirstlane((int)(st + 1024u * j)), hvoff[k >= 4 ? k - 4 : 0] + (unsigned)(kt * 32));
-      }
-    }
-  };
-  issue(0, 0);
-  if (nchunks > 1) issue(1, STAGEB);
-
-  // this lane's pixel in each of its two pixel tiles (column of the MFMA result)
-  unsigned pixoff[WPT];
-  int hp0[WPT];
-#pragma unroll
-  for (int pt = 0; pt < WPT; ++pt) {
-    const int pm = (wpx * WPT + pt) * 32 + li;
-    const int pr = pm / TW, pc = pm % TW;
-    const int oy = oy0 + pr, ox = ox0 + pc;
-    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
-    hp0[pt] = pr * HW + pc;
-  }
-
-  // accumulators start at bias + residual: the epilogue is stores only
-  f32x16 acc[WCT][WPT];
-  {
-    const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
-#pragma unroll
-    for (int ct = 0; ct < WCT; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
-        float bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
-#pragma unroll
-        for (int pt = 0; pt < WPT; ++pt) {
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.residual) {
-            const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
-            rv[0] = bf16_lo(v.x); rv[1] = bf16_hi(v.x); rv[2] = bf16_lo(v.y); rv[3] = bf16_hi(v.y);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ct][pt][4 * g + j] = bv[j] + rv[j];
-        }
-      }
-  }
-
-  // operand reads of step `tap` from the stage at LDS address sa: weight fragments are lane-linear, pixel fragments swizzled
-  const unsigned a_lane = (unsigned)(wco * WCT) * 1024u + lane16;
-  auto load_ab = [&](unsigned sa, int tap, bf16x8 (&a)[WCT], bf16x8 (&b)[WPT]) {
-#pragma unroll
-    for (int ct = 0; ct < WCT; ++ct) a[ct] = frag_from_u32x4(lds_ld128(sa + a_lane + (unsigned)((tap * 4 + ct) * 1024)));
-    const int toff = (tap / 3) * HW + (tap % 3);
-#pragma unroll
-    for (int pt = 0; pt < WPT; ++pt) {
-      const unsigned px = (unsigned)(hp0[pt] + toff);
-      b[pt] = frag_from_u32x4(lds_ld128(sa + HALO_OFF + px * 32u + ((((px >> 3) ^ (unsigned)h) & 1u) << 4)));
-    }
-  };
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned cur = 0, nxt = STAGEB, fre = 2 * STAGEB;
-  constexpr int RS = 3;                                 // steps in flight (operands of step s + 2 are requested before step s multiplies)
-  for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 2 < nchunks) issue(ch + 2, fre);           // the stage chunk ch - 1 left: its last reads ended before the barrier above
-    const unsigned sa = lds0 + cur;
-    bf16x8 abuf[RS][WCT], bbuf[RS][WPT];
-    load_ab(sa, 0, abuf[0], bbuf[0]);
-    load_ab(sa, 1, abuf[1], bbuf[1]);
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      if (tap + 2 < TAPS) load_ab(sa, tap + 2, abuf[(tap + 2) % RS], bbuf[(tap + 2) % RS]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ct = 0; ct < WCT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(abuf[tap % RS][ct], bbuf[tap % RS][pt], acc[ct][pt]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    { const unsigned o = cur; cur = nxt; nxt = fre; fre = o; }
-    // The batch issued at the top of THIS chunk is for the chunk after next: only the previous batch has to have landed now.  A fetch
-    // gets two chunk periods (HBM latency is longer than one).
-    if (ch + 2 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue: stores only ------------------------------------------------------------------------------------------------
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      static_cast<char*>(p.y) + (int64_t)n * p.Ho * p.Wo * p.Cout * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
-#pragma unroll
-  for (int ct = 0; ct < WCT; ++ct)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
-#pragma unroll
-      for (int pt = 0; pt < WPT; ++pt) {
-        if (p.out_f32) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[ct][pt][4 * g + j]), yrsrc, off, 0, 0);
-          }
-        } else {
-          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
-          u32x2 v;
-          v.x = pack_bf16x2(acc[ct][pt][4 * g + 0], acc[ct][pt][4 * g + 1]);
-          v.y = pack_bf16x2(acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
-        }
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// 128 x 128 register tiles: block = 16 x 32 output pixels x 128 output channels, FOUR waves (one per SIMD; the 256 accumulator
-// registers of a 4 x 4 grid of MFMA tiles each, in AGPRs), 16 input channels per chunk.
-//
-// Why this shape.  (1) Every LDS-staged variant above paid for its LDS-DMA pieces: a `buffer_load ... lds` costs the issuing wave
-// 60-185 cycles (MI355X_MICROARCH.md), and weights + halo through LDS are 48-56 pieces per chunk -- 30-50 % of the chunk's MFMA time.
-// (2) A weight fragment (1 KiB per tap, 16 ci, 32 co) fetched straight from L2 into registers costs one vector-memory instruction
-// that hides in an MFMA gap, but with 64 x 64 wave tiles it feeds two MFMAs only and the weight stream of a whole chip nears the L2's
-// bandwidth.  Here a fragment feeds FOUR MFMAs (four pixel tiles per wave), the chunk's 36 fragments live in 144 VGPRs and are
-// refilled in place for the next chunk right behind their last use, and only the halo (18 x 34 pixels x 16 channels: five pieces per
-// wave) goes through LDS, two chunks ahead in a ring of three 20 KiB stages.  (3) vmcnt retires in order: all vector memory of the
-// loop is issued from inline asm and awaited by hand -- a fragment with exactly the 32 younger refills + 5 halo pieces in flight, the
-// halo of the next chunk with the 36 refills + 5 pieces issued since.
-// ------------------------------------------------------------------------------------------------------------------------
-// -DODVAE_BIG_ABL=<bits>: timing-only ablations (wrong results): 1 no weight refills / waits, 2 no halo DMA / wait, 4 no barrier, 8 pixel fragments read once per chunk
-#ifndef ODVAE_BIG_ABL
-#define ODVAE_BIG_ABL 0
-#endif
-__global__ __launch_bounds__(256) void conv_bf16_big_kernel(ConvB p) {
-  constexpr int TAPS = 9, TH = 16, TWB = 32, HWB = TWB + 2, HPIX = (TH + 2) * HWB;
-  constexpr int HPIECES = (HPIX * 2 + 63) / 64;       // 20 halo pieces per chunk
-  static_assert(HPIECES % 4 == 0, "whole pieces per wave");
-  constexpr int HPW = HPIECES / 4;                    // five per wave
-  constexpr unsigned HSTAGE = HPIECES * 1024;
-  constexpr int WCT = 4, WPT = 4, NFR = TAPS * WCT;   // 36 weight fragments per chunk
-  extern __shared__ __attribute__((aligned(1024))) bf16_t smem[];
-  const unsigned lds0 = lds_addr_of(smem);
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int wpx = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  int t = p.xcd ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
-  const int oy0 = ty * TH, ox0 = tx * TWB;
-  const int co0 = blockIdx.y * 128;
-  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-  const int esz = p.out_f32 ? 4 : 2;
-  const unsigned OOB = 0x7FFFFFF0u;
-  const int KT = p.CinP / 16, CT = p.CoutP / 32;
-  const int nchunks = KT;
-
-  const i32x4_t xw = rsrc_words(p.x + (int64_t)n * p.Hi * p.Wi * p.Cin, (unsigned)(p.Hi * p.Wi * p.Cin * 2));
-  const i32x4_t ww = rsrc_words(p.wpk, (unsigned)(TAPS * KT * CT * 1024));
-  unsigned hvoff[HPW];
-#pragma unroll
-  for (int q = 0; q < HPW; ++q) {
-    const int slot = 64 * (wpx + 4 * q) + lane;
-    const int px = slot >> 1, half = (slot & 1) ^ ((px >> 3) & 1);
-    const int iy = iy0 + px / HWB, ix = ix0 + px % HWB;
-    const bool ok = px < HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-    hvoff[q] = ok ? (unsigned)(((iy * p.Wi + ix) * p.Cin + 8 * half) * 2) : OOB;
-  }
-  const unsigned lane16 = lane * 16;
-  // halo pieces of chunk kt -> stage hst; past the last chunk the same five instructions run against an empty descriptor (zeros land
-  // in a stage nobody reads any more), so that the number of operations in flight is the same in every chunk
-  auto issue_h = [&](int kt, unsigned hst) {
-    i32x4_t r = xw;
-    r.z = kt < nchunks ? xw.z : 0;
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(kt < nchunks ? kt * 32 : 0);
-#pragma unroll
-    for (int q = 0; q < HPW; ++q)
-      lds_dma16_s(r, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + hst + 1024u * (wpx + 4 * q))), hvoff[q], soff);
-  };
-  // weight fragment (tap, ct) of chunk kt -> registers
-  u32x4 wf[TAPS][WCT];
-  auto load_w = [&](int kt, int tap, int ct, u32x4& dst) {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((tap * KT + kt) * CT + co0 / 32 + ct) * 1024);
-    // (no s_nop in front: `soff` is the result of scalar arithmetic here -- the kernel has no SGPR spills, checked in the build's
-    // register statistics -- and the four MFMAs in front of every refill cover a VALU write anyway)
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(lane16), "s"(ww), "s"(soff) : "memory");
-  };
-  issue_h(0, 0);
-#pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-    for (int ct = 0; ct < WCT; ++ct) load_w(0, tap, ct, wf[tap][ct]);
-  issue_h(1, HSTAGE);
-
-  // this lane's pixel in each of its four pixel tiles (one tile = one row of 32 pixels; column of the MFMA result)
-  unsigned pixoff[WPT];
-  unsigned hp0[WPT];
-#pragma unroll
-  for (int pt = 0; pt < WPT; ++pt) {
-    const int pr = wpx * WPT + pt, pc = li;
-    const int oy = oy0 + pr, ox = ox0 + pc;
-    pixoff[pt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)((oy * p.Wo + ox) * p.Cout) : OOB;
-    hp0[pt] = (unsigned)(pr * HWB + pc);
-  }
-
-  // With one wave per SIMD nothing hides a long prologue: the accumulators start at zero (bias and residual join in the epilogue, whose
-  // loads are requested in batches)
-  f32x16 acc[WCT][WPT];
-#pragma unroll
-  for (int ct = 0; ct < WCT; ++ct)
-#pragma unroll
-    for (int pt = 0; pt < WPT; ++pt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-
-  auto load_px = [&](unsigned ha, int tap, bf16x8 (&b)[WPT]) {
-    const unsigned toff = (unsigned)((tap / 3) * HWB + (tap % 3));
-#pragma unroll
-    for (int pt = 0; pt < WPT; ++pt) {
-      const unsigned px = hp0[pt] + toff;
-      b[pt] = frag_from_u32x4(lds_ld128(ha + px * 32u + ((((px >> 3) ^ (unsigned)h) & 1u) << 4)));
-    }
-  };
-
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HPW) : "memory");      // halo 0 and the 36 fragments (the five pieces of halo 1 stay in flight)
-  __syncthreads();
-  unsigned hcur = 0, hnxt = HSTAGE, hfre = 2 * HSTAGE;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int chn = ch + 1 < nchunks ? ch + 1 : 0;               // past the last chunk: a harmless reload
-    const unsigned ha = lds0 + hcur;
-    bf16x8 bbuf[2][WPT];
-    load_px(ha, 0, bbuf[0]);
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      if (tap + 1 < TAPS && !(ODVAE_BIG_ABL & 8)) load_px(ha, tap + 1, bbuf[(tap + 1) & 1]);
-      if (ODVAE_BIG_ABL & 8) { for (int pt = 0; pt < WPT; ++pt) bbuf[(tap + 1) & 1][pt] = bbuf[tap & 1][pt]; }
-      // fragments of this tap: requested one chunk ago; younger than them: 4 (8 - tap) refills + 5 halo pieces + 4 tap refills = 37
-      if (!(ODVAE_BIG_ABL & 3))
-      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wf[tap][0]), "+v"(wf[tap][1]), "+v"(wf[tap][2]), "+v"(wf[tap][3]) : "n"(NFR - WCT + HPW) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ct = 0; ct < WCT; ++ct) {      // four MFMAs per fragment, its refill for the next chunk right behind them
-#pragma unroll
-        for (int pt = 0; pt < WPT; ++pt) acc[ct][pt] = mfma_bf16(frag_from_u32x4(wf[tap][ct]), bbuf[tap & 1][pt], acc[ct][pt]);
-        if (!(ODVAE_BIG_ABL & 1)) load_w(chn, tap, ct, wf[tap][ct]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (!(ODVAE_BIG_ABL & 2)) issue_h(ch + 2, hfre);          // the stage chunk ch - 1 read: its reads ended before the barrier above
-    { const unsigned o = hcur; hcur = hnxt; hnxt = hfre; hfre = o; }
-    if (ODVAE_BIG_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFR + HPW) : "memory");      // halo ch+1 (older than this chunk's 36 refills + 5 pieces) has landed
-    if (!(ODVAE_BIG_ABL & 4)) __syncthreads();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the refills past the last chunk still write registers
-
-  // ---- epilogue: bias (one 16-byte load per (channel tile, quad)) and residual requested in batches, then stores -----------------
-  const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      static_cast<char*>(p.y) + img * esz, 0, p.Ho * p.Wo * p.Cout * esz, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.bias ? p.bias : reinterpret_cast<const float*>(p.x)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
-#pragma unroll
-  for (int ct = 0; ct < WCT; ++ct) {
-    u32x4 bq[4];
-    u32x2 rq[4][WPT];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = co0 + ct * 32 + 8 * g + 4 * h;
-      bq[g] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, co < p.Cout ? (unsigned)co * 4u : OOB, 0, 0);     // (Cout % 4 == 0: whole quads)
-#pragma unroll
-      for (int pt = 0; pt < WPT; ++pt) rq[g][pt] = u32x2{0u, 0u};
-      if (p.residual) {
-#pragma unroll
-        for (int pt = 0; pt < WPT; ++pt)
-          rq[g][pt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB, 0, 0));
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = co0 + ct * 32 + 8 * g + 4 * h;
-      const float b0 = __uint_as_float(bq[g].x), b1 = __uint_as_float(bq[g].y), b2 = __uint_as_float(bq[g].z), b3 = __uint_as_float(bq[g].w);
-#pragma unroll
-      for (int pt = 0; pt < WPT; ++pt) {
-        const float v0 = acc[ct][pt][4 * g + 0] + b0 + bf16_lo(rq[g][pt].x), v1 = acc[ct][pt][4 * g + 1] + b1 + bf16_hi(rq[g][pt].x);
-        const float v2 = acc[ct][pt][4 * g + 2] + b2 + bf16_lo(rq[g][pt].y), v3 = acc[ct][pt][4 * g + 3] + b3 + bf16_hi(rq[g][pt].y);
-        if (p.out_f32) {
-          const float vv[4] = {v0, v1, v2, v3};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned off = (pixoff[pt] != OOB && co + j < p.Cout) ? (pixoff[pt] + (unsigned)(co + j)) * 4u : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[j]), yrsrc, off, 0, 0);
-          }
-        } else {
-          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
-          u32x2 v;
-          v.x = pack_bf16x2(v0, v1);
-          v.y = pack_bf16x2(v2, v3);
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned int, v), yrsrc, off, 0, 0);
-        }
+          for (int w = 0; w < 2; ++w) { a += red[(w * 32 + tid * rpg + j) * 2]; b += red[(w * 32 + tid * rpg + j) * 2 + 1]; }
+        float* dst = p.gn_partial + (((int64_t)n * (p.tiles_x * p.tiles_y) + ty * p.tiles_x + tx) * p.gn_groups + grp) * 2;
+        dst[0] = a; dst[1] = b;
       }
     }
   }
 }
+
+// (Rounds 2 and 3 built three more forms of the stride-1 3x3 kernel and measured each against the one above: a 16 x 16-pixel tile with an
+// LDS-DMA halo ring, +3-7 % per layer; weights AND halo through a three-stage LDS ring, -7 %; 128 x 128 register tiles with in-place
+// weight refills, +2-9 % per layer -- all three equal to it over a whole step.  They were removed in round 4; what they showed -- a
+// wave's vector-memory operations complete in issue order, the MFMA-only floor of this loop is 0.55 of the nominal bf16 peak at the
+// clock the chip holds -- is kept in DESIGN.md 9 and profiles/r03_conv_bf16_{wide_pmc,big_tile}.txt.)
 
 // OIHW f32 (kh x kw = 3x3 or 1x1) -> bf16 fragment packs.
 //   fwd:   reduce over Cin, rows = Cout:   W[tap][co][ci]
@@ -817,32 +322,24 @@ __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int
 
 int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX, int TH, int MINW = 1>
+template <int MODE, int KC, int WCT, int WPT, int WAVES_CO, int WAVES_PX, int TH, int MINW = 1, bool STATS = false>
 void launch_cfg(const ConvB& p, dim3 grid, hipStream_t st) {
   constexpr int bytes = 2 * HaloB<MODE, TH>::H * HaloB<MODE, TH>::W * (KC + 8) * 2;
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX, TH, MINW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX, TH, MINW, STATS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     once = true;
   }
-  hipLaunchKernelGGL((conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX, TH, MINW>), grid, dim3(256), bytes, st, p);
+  hipLaunchKernelGGL((conv_bf16_kernel<MODE, KC, WCT, WPT, WAVES_CO, WAVES_PX, TH, MINW, STATS>), grid, dim3(256), bytes, st, p);
 }
 
 template <int MODE, int KC>
 void launch_by_cout(ConvB& p, hipStream_t st) {
-  // A/B switch.  Measured (bench.py --bf16, B=32, 256x256): the wide tile runs the family at 365 TFLOP/s against 646 for the
-  // 128-pixel tile -- one 4-wave block per CU (424 registers, 93 KB of LDS) has nothing to overlap its prologue, barriers and
-  // epilogue with, which costs more than the halved weight traffic saves.  Off by default.
-  static const bool wide = getenv("ODVAE_CONV_BF16_WIDE") != nullptr;
-  if constexpr (MODE == 0 || MODE == 4) {
-    if (p.Cout > 64 && p.Ho >= 16 && wide) {     // wide tile: 16 x 16 pixels x 128 channels, 64 co x 128 px per wave
-      p.tiles_y = ceil_div(p.Ho, 16);
-      launch_cfg<MODE, KC, 2, 4, 2, 2, 16>(p, dim3(p.N * p.tiles_x * p.tiles_y, ceil_div(p.Cout, 128)), st);
-      return;
-    }
-  }
   const int tiles = p.N * p.tiles_x * p.tiles_y;
+  if constexpr (MODE == 0) {
+    if (p.gn_partial) { launch_cfg<MODE, KC, 2, 2, 2, 2, 8, 1, true>(p, dim3(tiles, ceil_div(p.Cout, 128)), st); return; }
+  }
   if (p.Cout > 64)      launch_cfg<MODE, KC, 2, 2, 2, 2, 8>(p, dim3(tiles, ceil_div(p.Cout, 128)), st);
   else if (p.Cout > 32) launch_cfg<MODE, KC, 2, 1, 1, 4, 8>(p, dim3(tiles, 1), st);
   else                  launch_cfg<MODE, KC, 1, 1, 1, 4, 8>(p, dim3(tiles, 1), st);
@@ -850,14 +347,7 @@ void launch_by_cout(ConvB& p, hipStream_t st) {
 
 }  // namespace
 
-static int g_wide_tile = -1;   // -1: not chosen yet (environment decides at the first call)
-
 extern "C" {
-
-// Tile of the stride-1 3x3 convs with Cout > 64 and Ho >= 16: 0 = 8 x 16 pixels (conv_bf16_kernel), 1 = 16 x 16 with an LDS-DMA halo
-// ring and weights from L2 (conv_bf16_wide_kernel, Cin % 32 == 0), 2 = 16 x 16 with weights AND halo through LDS
-// (conv_bf16_lds_kernel, Cin % 16 == 0).  ODVAE_CONV_BF16_WIDE2 presets it.  Returns the previous setting (-1 = environment not read yet).
-int odvae_conv_bf16_select_wide_tile(int on) { const int prev = g_wide_tile; g_wide_tile = on < 0 ? 0 : (on > 3 ? 3 : on); return prev; }
 
 // reduction-channel padding (16 per MFMA k-step; the kernel walks chunks of 32 or 64) and output-channel padding of a pack
 int odvae_conv_bf16_reduce_pad(int c) { return c % 64 == 0 ? c : pad_to(c, 32); }
@@ -884,8 +374,35 @@ int odvae_conv_pack_bf16(const float* w, int Cout, int Cin, int taps, void* fwd_
 // y = conv(x) (+ bias) (+ residual).  x bf16 NHWC [N][Hi][Wi][Cin] (Cin % 8 == 0), pack from odvae_conv_pack_bf16 with
 // (reduce = Cin, out = Cout), bias f32 [Cout] or NULL, residual bf16 [N][Ho][Wo][Cout] or NULL, y bf16 (out_f32 = 0; needs
 // Cout % 4 == 0) or f32 (out_f32 = 1, any Cout).  mode 0..3 as in odvae_conv3x3_f32; mode 4 = 1x1 on [N][Hi][Wi] = [1][M/16][16].
+static int conv_bf16_impl(int mode, const void* x, int N, int Hi, int Wi, int Cin, const void* pack, int Cout, const float* bias,
+                          const void* residual, void* y, int Ho, int Wo, int out_f32, float* gn_partial, int gn_groups, void* stream);
+
 int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, const void* pack, int Cout, const float* bias,
                     const void* residual, void* y, int Ho, int Wo, int out_f32, void* stream) {
+  return conv_bf16_impl(mode, x, N, Hi, Wi, Cin, pack, Cout, bias, residual, y, Ho, Wo, out_f32, nullptr, 0, stream);
+}
+
+// tiles per image of the stride-1 3x3 kernel = the chunk count of its GroupNorm partials
+int odvae_conv_bf16_stats_chunks(int H, int W) { return ceil_div(H, 8) * ceil_div(W, TW); }
+// shapes whose stride-1 3x3 conv can leave the statistics: more than 64 output channels, whole groups per 128-channel block, groups of
+// whole 4-channel runs
+int odvae_conv_bf16_stats_supported(int Cout, int gn_groups) {
+  if (gn_groups <= 0 || Cout <= 64 || Cout % gn_groups != 0) return 0;
+  const int cpg = Cout / gn_groups;
+  return cpg % 4 == 0 && cpg <= 128 && 128 % cpg == 0;
+}
+
+// The stride-1 3x3 conv (mode 0, bf16 output) whose epilogue also leaves the GroupNorm statistics of y for the layer that reads it:
+// gn_partial [N][odvae_conv_bf16_stats_chunks(H, W)][gn_groups][2] = (sum, sum of squares) of the bf16-rounded y per tile and channel
+// group, every slot written by exactly one block -- the input of odvae_groupnorm_fwd_partials_bf16 (no statistics pass).
+int odvae_conv_bf16_stats(const void* x, int N, int H, int W, int Cin, const void* pack, int Cout, const float* bias, const void* residual,
+                          void* y, float* gn_partial, int gn_groups, void* stream) {
+  ODVAE_CHECK_ARG(gn_partial && odvae_conv_bf16_stats_supported(Cout, gn_groups), "conv_bf16_stats: Cout = %d with %d groups is not offered", Cout, gn_groups);
+  return conv_bf16_impl(0, x, N, H, W, Cin, pack, Cout, bias, residual, y, H, W, 0, gn_partial, gn_groups, stream);
+}
+
+static int conv_bf16_impl(int mode, const void* x, int N, int Hi, int Wi, int Cin, const void* pack, int Cout, const float* bias,
+                          const void* residual, void* y, int Ho, int Wo, int out_f32, float* gn_partial, int gn_groups, void* stream) {
   ODVAE_CHECK_ARG(mode >= 0 && mode <= 4, "conv_bf16: mode %d", mode);
   ODVAE_CHECK_ARG(x && pack && y && N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv_bf16: null or empty operand");
   ODVAE_CHECK_ARG(Cin % 8 == 0, "conv_bf16: Cin = %d must be a multiple of 8 (16-byte channel vectors)", Cin);
@@ -906,60 +423,12 @@ int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, con
   p.N = N; p.Hi = Hi; p.Wi = Wi; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.CinP = odvae_conv_bf16_reduce_pad(Cin); p.CoutP = odvae_conv_bf16_out_pad(Cout);
   p.tiles_x = ceil_div(Wo, TW); p.tiles_y = ceil_div(Ho, 8); p.out_f32 = out_f32;
+  p.gn_partial = gn_partial; p.gn_groups = gn_groups; p.gn_cpg = gn_groups > 0 ? Cout / gn_groups : 0;
   static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
   p.xcd = xcd ? 1 : 0;
   ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool k64 = p.CinP % 64 == 0;
-  // ODVAE_CONV_BF16_WIDE2=1: stride-1 3x3 convs with more than 64 output channels and whole 32-channel chunks on the wide tile
-  // (conv_bf16_wide_kernel).  Off by default: measured on the layers it is 3-7 % faster than the 128-pixel tile (795 vs 744 TFLOP/s at
-  // 128 -> 128 @256x256, 951 vs 920 at 256 -> 256 @128x128, B=32), over a whole bf16 step the two are equal (405.6 vs 406.2 images/s at
-  // 256x256, 70.6 vs 70.8 at 512x512).  What it showed (timing-only build without the in-loop halo DMA: +15 / +22 %): a wave's vector
-  // memory operations complete in issue order, so every weight load issued behind the halo fetch of the chunk two ahead waits for that
-  // fetch's HBM latency -- two steps of weight prefetch do not cover it.  The same holds for the register-staged halo loads of
-  // conv_bf16_kernel.  The structural fix is weights through LDS as well (no per-step global loads); DESIGN.md 9.
-  if (g_wide_tile < 0) g_wide_tile = getenv("ODVAE_CONV_BF16_WIDE2") ? atoi(getenv("ODVAE_CONV_BF16_WIDE2")) : 0;
-  const int wide2 = g_wide_tile;
-  if (mode == 0 && wide2 == 3 && Cout > 64 && Cout % 4 == 0 && Cin % 16 == 0 && Ho >= 16 && Wo >= 32) {
-    p.tiles_x = ceil_div(Wo, 32);
-    p.tiles_y = ceil_div(Ho, 16);
-    constexpr int lds_bytes = 3 * 20 * 1024;
-    static bool once_b = false;
-    if (!once_b) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      once_b = true;
-    }
-    ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
-    hipLaunchKernelGGL(conv_bf16_big_kernel, dim3(N * p.tiles_x * p.tiles_y, ceil_div(Cout, 128)), dim3(256), lds_bytes, st, p);
-    ODVAE_LAUNCH_CHECK("conv_bf16 (128 x 128 register tiles)");
-    return ODVAE_OK;
-  }
-  if (mode == 0 && wide2 == 2 && Cout > 64 && Cin % 16 == 0 && Ho >= 16) {
-    p.tiles_y = ceil_div(Ho, 16);
-    constexpr int lds_bytes = 3 * 48 * 1024;
-    static bool once_l = false;
-    if (!once_l) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      once_l = true;
-    }
-    ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
-    hipLaunchKernelGGL(conv_bf16_lds_kernel, dim3(N * p.tiles_x * p.tiles_y, ceil_div(Cout, 128)), dim3(512), lds_bytes, st, p);
-    ODVAE_LAUNCH_CHECK("conv_bf16 (all-LDS tile)");
-    return ODVAE_OK;
-  }
-  if (mode == 0 && wide2 == 1 && Cout > 64 && Cin % 32 == 0 && Ho >= 16) {
-    p.tiles_y = ceil_div(Ho, 16);
-    constexpr int lds_bytes = 3 * 21 * 1024;
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      once = true;
-    }
-    ODVAE_CHECK_ARG((int64_t)N * p.tiles_x * p.tiles_y < 0x7FFFFFFFll, "conv_bf16: too many tiles");
-    hipLaunchKernelGGL(conv_bf16_wide_kernel, dim3(N * p.tiles_x * p.tiles_y, ceil_div(Cout, 128)), dim3(256), lds_bytes, st, p);
-    ODVAE_LAUNCH_CHECK("conv_bf16 (wide tile)");
-    return ODVAE_OK;
-  }
   switch (mode) {
     // (32-channel chunks at three blocks per CU -- __launch_bounds__(256, 3): 168 registers, 29 KB of LDS -- measured the same as
     // 64-channel chunks at two blocks per CU: 747 vs 740 TFLOP/s at 128 channels, B=32)

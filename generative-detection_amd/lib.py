@@ -54,6 +54,8 @@ PROTOTYPES = {
     "odvae_groupnorm_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_fwd_partials_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _I, _P]),
     "odvae_groupnorm_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "odvae_groupnorm_select_backward": (_I, [_I]),
+    "odvae_groupnorm_fused_timeouts": (_I, []),
     "odvae_softmax_rows_f32": (_I, [_P, _P, _L, _I, _F, _P]),
     "odvae_softmax_rows_bwd_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "odvae_upsample2x_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -89,12 +91,14 @@ PROTOTYPES = {
     "odvae_linear_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "odvae_linear_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P]),
     # bf16 mixed-precision path
-    "odvae_conv_bf16_select_wide_tile": (_I, [_I]),
     "odvae_conv_bf16_reduce_pad": (_I, [_I]),
     "odvae_conv_bf16_out_pad": (_I, [_I]),
     "odvae_conv_bf16_pack_elems": (_Z, [_I, _I, _I]),
     "odvae_conv_pack_bf16": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "odvae_conv_bf16": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "odvae_conv_bf16_stats_chunks": (_I, [_I, _I]),
+    "odvae_conv_bf16_stats_supported": (_I, [_I, _I]),
+    "odvae_conv_bf16_stats": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "odvae_conv_wgrad_bf16_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv_wgrad_bf16": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "odvae_flash_attn_supported": (_I, [_I, _I, _I]),
@@ -102,6 +106,7 @@ PROTOTYPES = {
     "odvae_flash_attn_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "odvae_groupnorm_bf16_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "odvae_groupnorm_fwd_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
+    "odvae_groupnorm_fwd_partials_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _I, _P]),
     "odvae_groupnorm_bwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "odvae_cast_pad_bf16": (_I, [_P, _L, _I, _I, _P, _P]),
     "odvae_cast_f32_from_bf16": (_I, [_P, _L, _P, _P]),

@@ -116,7 +116,14 @@ KERNEL_EVENTS = _KernelEvents()
 class _PackCache:
     """Weight packs keyed by (storage pointer, tensor version, optimizer epoch): a conv's forward and data-gradient packs
     are built together, once per weight update, instead of once per call.  FusedAdam updates parameters from a raw
-    kernel (no torch version bump), so it advances `epoch` itself."""
+    kernel (no torch version bump), so it advances `epoch` itself.
+    A stale entry is REPACKED INTO ITS OWN BUFFERS (same weight object, same pack kind, hence same sizes): the per-step churn of
+    ~180 small allocations and frees kept the caching allocator's small pool fragmenting, and a training step in steady state asked the
+    driver for fresh 2 MB segments once or twice (hipMalloc: a device synchronisation -- DESIGN.md 4, the bf16 256x256 side run).
+    A graph built before a weight update must not be back-propagated after it: its data-gradient pack now holds the NEW weights
+    (torch would raise its "modified by an inplace operation" error there; `check_epoch` raises the same way)."""
+
+    INPLACE = os.environ.get("ODVAE_PACK_INPLACE", "1") != "0"
 
     def __init__(self):
         self.epoch = 0
@@ -129,38 +136,54 @@ class _PackCache:
         key = (id(weight), up)
         tag = (weight.data_ptr(), weight._version, self.epoch)
         hit = self.store.get(key)
-        if hit is not None and hit[0]() is weight and hit[1] == tag and (hit[3] is not None or not want_dgrad):
+        same = hit is not None and hit[0]() is weight
+        if same and hit[1] == tag and (hit[3] is not None or not want_dgrad):
             return hit[2], hit[3]
-        fwd, dgr = _pack_conv3x3_now(weight, True, want_dgrad, up)
-        if len(self.store) > 4096:   # transient weights (tests): drop entries whose tensor is gone
-            self.store = {k: v for k, v in self.store.items() if v[0]() is not None}
-        self.store[key] = (weakref.ref(weight), tag, fwd, dgr)
+        reuse = None
+        if same and self.INPLACE and hit[4] == (tuple(weight.shape), weight.device) and (hit[3] is not None or not want_dgrad):
+            reuse = (hit[2], hit[3])          # refill the buffers this weight's packs already live in
+            want_dgrad = hit[3] is not None
+        fwd, dgr = _pack_conv3x3_now(weight, True, want_dgrad, up, into=reuse)
+        # An entry dies with its weight tensor.  AttnBlock builds its [3C, C] q/k/v weight with torch.cat on every forward: each of
+        # those temporaries left its two packs behind (round 3 purged dead entries only past 4 096 of them), 14 per step in the bf16
+        # path, 6-10 MB that the allocator had to find -- a few fresh hipMalloc calls per step, each a device synchronisation; the
+        # f32 path never saw it because its 1x1 convs read the weight as it is.
+        store = self.store
+        ref = weakref.ref(weight, lambda r, k=key: store.pop(k, None) if (store.get(k) or (None,))[0] is r else None)
+        store[key] = (ref, tag, fwd, dgr, (tuple(weight.shape), weight.device))
         return fwd, dgr
+
+    def check_epoch(self, epoch, what):
+        if epoch != self.epoch:
+            raise RuntimeError("%s: the weights were updated (optimizer step) between this graph's forward and its backward; the "
+                               "cached weight packs now hold the new weights" % what)
 
 
 PACK_CACHE = _PackCache()
 
 
-def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False, up=False):
+def _pack_conv3x3_now(weight, want_fwd=True, want_dgrad=False, up=False, into=None):
     """up=True: the 16-tap packs of an Upsample conv (taps that hit the same low-res pixel pre-summed, modes 5 / 6);
-    up="wino": the Winograd F(2x2,3x3) packs U = G g G^T of a stride-1 conv (conv3x3_wino_f32.hip)."""
+    up="wino": the Winograd F(2x2,3x3) packs U = G g G^T of a stride-1 conv (conv3x3_wino_f32.hip).
+    into=(fwd, dgr): refill these pack tensors (of the same weight and kind) instead of allocating."""
     L = _L()
+    ifwd, idgr = into if into is not None else (None, None)
     w = weight.detach().contiguous()
     _lib.require_device(w)
     cout, cin = w.shape[0], w.shape[1]
     if up == "bf16":   # bf16 MFMA-fragment packs of a 3x3 or 1x1 conv (conv_bf16.hip); master weights stay f32
         taps = w.shape[2] * w.shape[3]
-        fwd = torch.empty(L.odvae_conv_bf16_pack_elems(cin, cout, taps), dtype=BF16, device=w.device) if want_fwd else None
-        dgr = torch.empty(L.odvae_conv_bf16_pack_elems(cout, cin, taps), dtype=BF16, device=w.device) if want_dgrad else None
+        fwd = (ifwd if ifwd is not None else torch.empty(L.odvae_conv_bf16_pack_elems(cin, cout, taps), dtype=BF16, device=w.device)) if want_fwd else None
+        dgr = (idgr if idgr is not None else torch.empty(L.odvae_conv_bf16_pack_elems(cout, cin, taps), dtype=BF16, device=w.device)) if want_dgrad else None
         _lib.check(L.odvae_conv_pack_bf16(w.data_ptr(), cout, cin, taps, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv_pack_bf16")
         return fwd, dgr
     floats = (L.odvae_conv3x3_wino_pack_floats if up == "wino" else L.odvae_conv3x3_wino4_pack_floats if up == "wino4" else
               L.odvae_conv3x3_up_pack_floats if up else L.odvae_conv3x3_pack_floats)
     fwd = dgr = None
     if want_fwd:
-        fwd = torch.empty(floats(cin, cout), dtype=torch.float32, device=w.device)
+        fwd = ifwd if ifwd is not None else torch.empty(floats(cin, cout), dtype=torch.float32, device=w.device)
     if want_dgrad:
-        dgr = torch.empty(floats(cout, cin), dtype=torch.float32, device=w.device)
+        dgr = idgr if idgr is not None else torch.empty(floats(cout, cin), dtype=torch.float32, device=w.device)
     pack = (L.odvae_conv3x3_pack_wino_f32 if up == "wino" else L.odvae_conv3x3_pack_wino4_f32 if up == "wino4" else
             L.odvae_conv3x3_pack_up_f32 if up else L.odvae_conv3x3_pack_f32)
     _lib.check(pack(w.data_ptr(), cout, cin, _lib.ptr(fwd), _lib.ptr(dgr), _lib.stream_ptr()), "conv3x3_pack")
@@ -288,6 +311,7 @@ class _Conv3x3(Function):
         else:
             y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
         ctx.mode, ctx.up = mode, up
+        ctx.pack_epoch = PACK_CACHE.epoch
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -314,6 +338,7 @@ class _Conv3x3(Function):
         _, _, ho, wo = dy.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            PACK_CACHE.check_epoch(ctx.pack_epoch, "conv3x3 backward")
             _, dgr = pack_conv3x3(weight, False, True, ctx.up)
             if ctx.up in ("wino", "wino4"):
                 dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=ctx.up == "wino4")
@@ -363,6 +388,11 @@ def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=Fal
     if x.dtype == BF16:
         if relu:
             raise NotImplementedError("fused ReLU is only on the f32 path (the LPIPS-style VGG stack stays f32)")
+        if gn_stats and mode == 0 and not out_f32:
+            y, partial = _ConvB.apply(x, weight, bias, residual, mode, False, True)
+            if partial is not None:
+                y._gn_partials = (partial, y.data_ptr(), y._version, tuple(y.shape))
+            return y
         return _ConvB.apply(x, weight, bias, residual, mode, bool(out_f32))
     if gn_stats and not relu and mode == 0:
         y, partial = _Conv3x3.apply(x, weight, bias, residual, mode, relu, True)
@@ -665,14 +695,15 @@ def _gn_partials_of(x, groups):
     if ptr != x.data_ptr() or version != x._version or shape != tuple(x.shape) or p.device != x.device:
         return None      # the tensor was written to (or is not the conv's output any more): take the statistics pass
     n, _, h, w = x.shape
-    if p.shape[0] != n or p.shape[2] != groups or p.shape[1] != _L().odvae_conv3x3_wino4_stats_chunks(h, w):
+    chunks = _L().odvae_conv_bf16_stats_chunks(h, w) if x.dtype == BF16 else _L().odvae_conv3x3_wino4_stats_chunks(h, w)
+    if p.shape[0] != n or p.shape[2] != groups or p.shape[1] != chunks:
         return None
     return p
 
 
 def group_norm(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     if x.dtype == BF16:
-        return _GroupNormB.apply(x, gamma, beta, groups, eps, swish)
+        return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, False, _gn_partials_of(x, groups))
     return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, False, _gn_partials_of(x, groups))
 
 
@@ -681,7 +712,7 @@ def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     gradient returns into this node and is summed into dx inside the GroupNorm backward pass (one pass instead of
     autograd's separate 3-pass add)."""
     if x.dtype == BF16:
-        return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, True)
+        return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, True, _gn_partials_of(x, groups))
     return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True, _gn_partials_of(x, groups))
 
 
@@ -1112,7 +1143,7 @@ def lpips_layer_distance(f0, f1, lin_w):
 _I31 = 0x7FFFFFF0
 
 
-def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32, cin_alg=None):
+def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32, cin_alg=None, stats=False):
     """One odvae_conv_bf16 call.  mode 4 (1x1) flattens the pixels to [1][M/wi][wi]; images are processed in groups small enough
     for the 2 GiB buffer descriptors.  cin_alg: the reduction width the algorithm has (3 for conv_in, whose image is zero-padded to
     8 channels): the FLOP / byte figures handed to KERNEL_EVENTS are the direct-form work of SURVEY.md 8(d), not the padded work."""
@@ -1128,13 +1159,19 @@ def _conv_b_raw(mode, x, pack, cout, bias, residual, out_f32, cin_alg=None):
     esz = 4 if out_f32 else 2
     if mode != 4:
         tag = KERNEL_EVENTS.begin()
-        _lib.check(L.odvae_conv_bf16(mode, x.data_ptr(), n, hi, wi, cx, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
-                                     y.data_ptr(), ho, wo, int(out_f32), _lib.stream_ptr()), "conv_bf16(mode=%d)" % mode)
+        partial = None
+        if stats:     # (mode 0, bf16 output) the epilogue also leaves the GroupNorm statistics of y per output tile
+            partial = torch.empty(n, L.odvae_conv_bf16_stats_chunks(ho, wo), GN_GROUPS, 2, dtype=torch.float32, device=x.device)
+            _lib.check(L.odvae_conv_bf16_stats(x.data_ptr(), n, hi, wi, cx, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                                               y.data_ptr(), partial.data_ptr(), GN_GROUPS, _lib.stream_ptr()), "conv_bf16_stats")
+        else:
+            _lib.check(L.odvae_conv_bf16(mode, x.data_ptr(), n, hi, wi, cx, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                                         y.data_ptr(), ho, wo, int(out_f32), _lib.stream_ptr()), "conv_bf16(mode=%d)" % mode)
         ca = cin_alg or cx
         px = hi * wi if mode == 3 else ho * wo     # mode 3 (data gradient of the stride-2 conv): nine taps per LOW-res pixel
         KERNEL_EVENTS.end("conv_bf16", 2.0 * 9 * ca * cout * n * px, tag,
                           2.0 * n * hi * wi * ca + esz * n * ho * wo * cout * (2 if residual is not None else 1) + 2.0 * 9 * ca * cout)
-        return y
+        return (y, partial) if stats else y
     per = hi * wi
     grp = max(1, min(n, _I31 // max(per * cx * 2, per * cout * esz)))
     for a in range(0, n, grp):
@@ -1158,7 +1195,9 @@ class _ConvB(Function):
     (OIHW), their gradients come back in f32.  x may carry zero channels beyond weight.shape[1] (the 3-channel image padded to 8)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, mode, out_f32):
+    def forward(ctx, x, weight, bias, residual, mode, out_f32, gn_stats=False):
+        """gn_stats=True: returns (y, partials) -- partials [N][tiles][32][2], the GroupNorm statistics of y from the conv's own epilogue
+        (not differentiable), or None where the kernel does not offer them."""
         L = _L()
         x = _cl(x, BF16)
         res = _cl(residual, BF16) if residual is not None else None
@@ -1167,14 +1206,23 @@ class _ConvB(Function):
             raise ValueError("conv_bf16: input has %d channels, weight expects %d" % (x.shape[1], cin))
         fwd_pack, dpack = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), "bf16")
         b = bias.detach().contiguous() if bias is not None else None
-        y = _conv_b_raw(mode, x, fwd_pack, cout, b, res, out_f32, cin_alg=cin)
+        partial = None
+        if gn_stats and mode == 0 and not out_f32 and GN_FUSED_STATS and L.odvae_conv_bf16_stats_supported(cout, GN_GROUPS):
+            y, partial = _conv_b_raw(mode, x, fwd_pack, cout, b, res, out_f32, cin_alg=cin, stats=True)
+        else:
+            y = _conv_b_raw(mode, x, fwd_pack, cout, b, res, out_f32, cin_alg=cin)
         ctx.mode, ctx.has_bias, ctx.has_res, ctx.dpack = mode, bias is not None, residual is not None, dpack
+        ctx.pack_epoch = PACK_CACHE.epoch
         ctx.wshape = tuple(weight.shape)
         ctx.save_for_backward(x)
+        if gn_stats:
+            if partial is not None:
+                ctx.mark_non_differentiable(partial)
+            return y, partial
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         L = _L()
         (x,) = ctx.saved_tensors
         mode = ctx.mode
@@ -1191,6 +1239,7 @@ class _ConvB(Function):
         if ctx.needs_input_grad[0]:
             if cx != cin:
                 raise NotImplementedError("data gradient through a channel-padded input")
+            PACK_CACHE.check_epoch(ctx.pack_epoch, "conv_bf16 backward")
             if mode == 0:
                 dx = _conv_b_raw(0, dyb, ctx.dpack, cin, None, None, False)
             elif mode == 1:
@@ -1248,7 +1297,7 @@ class _ConvB(Function):
                 wp, wn = _ws(L.odvae_colsum_bf16_workspace_bytes(rows, cout), x)
                 _lib.check(L.odvae_colsum_bf16(dyb.data_ptr(), rows, cout, db.data_ptr(), wp, wn, _lib.stream_ptr()), "colsum_bf16")
         dres = dyb if ctx.has_res and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None
 
 
 WGRAD_1X1_GROUP = 0   # tests: force the image-group split of the 1x1 weight gradient at small sizes (0 = only past 2 GiB)
@@ -1296,7 +1345,7 @@ class _GroupNormB(Function):
     """GroupNorm(+swish) on bf16 activations: statistics and arithmetic in f32, one rounding on the way out."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False):
+    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False, partials=None):
         L = _L()
         x = _cl(x, BF16)
         n, c, h, w = x.shape
@@ -1304,10 +1353,15 @@ class _GroupNormB(Function):
         y = _new_cl(n, c, h, w, x, dtype=BF16)
         mean = torch.empty(n, groups, dtype=torch.float32, device=x.device)
         rstd = torch.empty(n, groups, dtype=torch.float32, device=x.device)
-        wp, wn = _ws(L.odvae_groupnorm_bf16_workspace_bytes(n, h * w, c, groups), x)
         tag = KERNEL_EVENTS.begin(secondary=True)
-        _lib.check(L.odvae_groupnorm_fwd_bf16(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps), int(swish),
-                                              y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn, _lib.stream_ptr()), "groupnorm_fwd_bf16")
+        if partials is not None and partials.shape[0] == n and partials.shape[2] == groups:
+            _lib.check(L.odvae_groupnorm_fwd_partials_bf16(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps), int(swish),
+                                                           y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), partials.data_ptr(),
+                                                           int(partials.shape[1]), _lib.stream_ptr()), "groupnorm_fwd_partials_bf16")
+        else:
+            wp, wn = _ws(L.odvae_groupnorm_bf16_workspace_bytes(n, h * w, c, groups), x)
+            _lib.check(L.odvae_groupnorm_fwd_bf16(x.data_ptr(), n, h * w, c, groups, g.data_ptr(), b.data_ptr(), float(eps), int(swish),
+                                                  y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), wp, wn, _lib.stream_ptr()), "groupnorm_fwd_bf16")
         KERNEL_EVENTS.end("groupnorm", 0.0, tag, 2.0 * 2 * n * h * w * c, issued=0.0)
         ctx.groups, ctx.swish = groups, int(swish)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
@@ -1321,7 +1375,7 @@ class _GroupNormB(Function):
         L = _L()
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if dy is None:
-            return dskip, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None
         dy = _cl(dy, BF16)
         if dskip is not None:
             dskip = _cl(dskip, BF16)
@@ -1336,7 +1390,7 @@ class _GroupNormB(Function):
                                               mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                               _lib.ptr(dskip), wp, wn, _lib.stream_ptr()), "groupnorm_bwd_bf16")
         KERNEL_EVENTS.end("groupnorm", 0.0, tag, 2.0 * (3 + (dskip is not None)) * n * h * w * c, issued=0.0)
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None
 
 
 class _FlashAttention(Function):

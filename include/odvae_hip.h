@@ -143,6 +143,13 @@ int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int 
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
                             float* dx, float* dgamma, float* dbeta, const float* dx_add,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* backward form of odvae_groupnorm_bwd_f32: -1 (default) the read-once kernel where ONE block holds a (sample, 32-channel slab) in its
+ * registers (HW <= 256; C % 32 == 0, whole groups per slab), reduce + apply (x and dy read twice) elsewhere; 0 always reduce + apply;
+ * 1 the read-once kernel on every shape it takes (teams of ceil(HW / 256) resident blocks that meet at a per-item barrier in L2 --
+ * measured slower than the two-kernel form on this chip for HW >= 1024, kept for A/B) or ODVAE_ERR_ARG.  Returns the previous setting. */
+int odvae_groupnorm_select_backward(int mode);
+/* team-barrier waits of the read-once kernels that gave up (0.2 s) since the library was loaded; synchronises the device.  Must be 0. */
+int odvae_groupnorm_fused_timeouts(void);
 /* dx_add (nullable, same shape as x): a second gradient reaching x (the ResnetBlock / AttnBlock skip connection,
    [UPSTREAM] model.py `return x + h`), summed into dx in the same pass instead of autograd's separate add kernel */
 
@@ -254,11 +261,6 @@ int odvae_linear_bwd_f32(const float* x, const float* w, const float* pre, const
  * on v_mfma_f32_32x32x16_bf16.  Every `void*` activation pointer below is bf16 unless the comment says otherwise. ================ */
 
 /* ---- conv_bf16.hip: 3x3 / 1x1 convolutions ([UPSTREAM] ldm model.py via feat_encoder.py:4, feat_decoder.py:4) ---------------- */
-/* Tile of the stride-1 3x3 convs with Cout > 64 and Ho >= 16: 0 = 8x16 pixels; 1 = 16x16 pixels, LDS-DMA halo ring, weights from L2
-   (Cin % 32 == 0); 2 = 16x16 pixels, weights and halo through LDS (Cin % 16 == 0); 3 = 16x32 pixels on 128x128 register tiles
-   (four waves, Cin % 16 == 0, Wo >= 32).  Returns the previous setting (-1: not chosen yet,
-   the environment variable ODVAE_CONV_BF16_WIDE2 decides at the first call). */
-int odvae_conv_bf16_select_wide_tile(int on);
 int odvae_conv_bf16_reduce_pad(int c);
 int odvae_conv_bf16_out_pad(int c);
 size_t odvae_conv_bf16_pack_elems(int reduce_c, int out_c, int taps);
@@ -270,6 +272,14 @@ int odvae_conv_pack_bf16(const float* w, int Cout, int Cin, int taps, void* fwd_
    [N][Ho][Wo][Cout] or NULL, y bf16 (out_f32 = 0, Cout % 4 == 0) or f32 (out_f32 = 1) */
 int odvae_conv_bf16(int mode, const void* x, int N, int Hi, int Wi, int Cin, const void* pack, int Cout, const float* bias,
                     const void* residual, void* y, int Ho, int Wo, int out_f32, void* stream);
+/* The stride-1 3x3 conv (mode 0, bf16 output) whose epilogue also leaves the GroupNorm statistics of y -- (sum, sum of squares) of the
+ * bf16-rounded values per output tile and channel group, gn_partial [N][odvae_conv_bf16_stats_chunks(H, W)][gn_groups][2], every slot
+ * written by exactly one block -- for odvae_groupnorm_fwd_partials_bf16.  odvae_conv_bf16_stats_supported: Cout > 64, groups of whole
+ * 4-channel runs that do not straddle a 128-channel block. */
+int odvae_conv_bf16_stats_chunks(int H, int W);
+int odvae_conv_bf16_stats_supported(int Cout, int gn_groups);
+int odvae_conv_bf16_stats(const void* x, int N, int H, int W, int Cin, const void* pack, int Cout, const float* bias, const void* residual,
+                          void* y, float* gn_partial, int gn_groups, void* stream);
 /* ---- conv_wgrad_bf16.hip: weight gradient, dw f32 OIHW, modes 0 / 1 / 2 / 4 as above; deterministic ---------------------------- */
 size_t odvae_conv_wgrad_bf16_workspace_bytes(int mode, int N, int Ho, int Wo, int Cin, int Cout);
 /* db f32 [Cout] (bias gradient = per-channel sum of dy) or NULL, produced in the same pass */
@@ -286,6 +296,9 @@ int odvae_flash_attn_bwd_bf16(const void* qkv, const void* o, const void* d_o, c
 size_t odvae_groupnorm_bf16_workspace_bytes(int N, int HW, int C, int G);
 int odvae_groupnorm_fwd_bf16(const void* x, int N, int HW, int C, int G, const float* gamma, const float* beta, float eps, int swish,
                              void* y, float* mean, float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+/* odvae_groupnorm_fwd_bf16 without its statistics pass: partial [N][chunks][G][2] as odvae_conv_bf16_stats left them */
+int odvae_groupnorm_fwd_partials_bf16(const void* x, int N, int HW, int C, int G, const float* gamma, const float* beta, float eps, int swish,
+                                      void* y, float* mean, float* rstd, const float* partial, int chunks, void* stream);
 int odvae_groupnorm_bwd_bf16(const void* x, const void* dy, int N, int HW, int C, int G, const float* gamma, const float* beta,
                              const float* mean, const float* rstd, int swish, void* dx, float* dgamma, float* dbeta, const void* dx_add,
                              void* workspace, size_t workspace_bytes, void* stream);

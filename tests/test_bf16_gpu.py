@@ -51,19 +51,11 @@ def ref_conv(mode, x, w, b):
     (0, 2, 64, 128, 16, 16), (0, 1, 128, 256, 12, 20), (0, 2, 32, 64, 8, 8), (0, 1, 256, 32, 8, 16), (0, 2, 96, 128, 8, 16),
     (1, 2, 64, 64, 16, 16), (1, 1, 128, 128, 24, 8), (2, 2, 64, 64, 8, 8), (2, 1, 128, 128, 6, 10), (4, 2, 64, 192, 8, 8),
     (4, 1, 256, 256, 16, 16), (4, 3, 32, 64, 4, 4),
-    # the wide tile (16 x 16 pixels x 128 channels, LDS-DMA halo ring): whole tiles, ragged tiles in both directions, one / two / four
-    # 32-channel chunks, two output-channel blocks, forward and (Cin > 64) data gradient
+    # larger maps: whole tiles, ragged tiles in both directions, one / two / four 32-channel chunks, two output-channel blocks
     (0, 2, 128, 128, 32, 32), (0, 1, 256, 256, 20, 36), (0, 1, 128, 256, 17, 16), (0, 3, 32, 128, 16, 48), (0, 1, 96, 192, 33, 18)])
-@pytest.mark.parametrize("wide", [0, 1, 2, 3], ids=["tile8x16", "tile16x16", "tile16x16-lds", "tile16x32-128x128regs"])
-def test_conv_bf16_fwd_bwd(hip_lib, mode, n, cin, cout, h, w, wide):
+def test_conv_bf16_fwd_bwd(hip_lib, mode, n, cin, cout, h, w):
     from odvae_amd import ops
-    if wide and not (mode == 0 and max(cin, cout) > 64 and h >= 16):
-        pytest.skip("shape never reaches the wide tile")
-    prev = hip_lib.odvae_conv_bf16_select_wide_tile(wide)
-    try:
-        _conv_bf16_fwd_bwd(ops, mode, n, cin, cout, h, w)
-    finally:
-        hip_lib.odvae_conv_bf16_select_wide_tile(max(prev, 0))
+    _conv_bf16_fwd_bwd(ops, mode, n, cin, cout, h, w)
 
 
 def _conv_bf16_fwd_bwd(ops, mode, n, cin, cout, h, w):
@@ -270,3 +262,45 @@ def test_attn_and_resnet_blocks_bf16(hip_lib):
                 assert p.grad.abs().max().item() <= 3e-2 * refp["v.bias"].grad.abs().max().item(), "attn dk.bias noise"
                 continue
             close(p.grad, refp[k].grad, 3e-2, "%s d%s" % (name, k))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,res", [(2, 64, 128, 16, 16, False), (3, 128, 256, 20, 36, True), (1, 256, 512, 8, 16, True),
+                                                (2, 128, 128, 33, 18, False), (4, 128, 128, 64, 64, True)])
+def test_groupnorm_statistics_from_the_bf16_conv_epilogue(hip_lib, monkeypatch, n, cin, cout, h, w, res):
+    """SURVEY.md 2.1, GroupNorm row, mixed-precision path: the stride-1 3x3 kernel leaves (sum, sum of squares) of its bf16-ROUNDED output
+    per output tile and channel group (4 / 8 / 16 channels per group, ragged tiles, two and four 128-channel blocks), and the GroupNorm
+    behind it runs finalize + apply only.  Checked: the partials against f64 sums of the tensor the conv wrote, the normalised output
+    and every gradient against the path with the statistics pass (same kernels otherwise), and against torch on the host."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(n + cin + cout + h)
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = 0.1 * torch.randn(cout, generator=g)
+    r = rb(torch.randn(n, cout, h, w, generator=g)) if res else None
+    gamma, beta = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    gy = cl_bf16(torch.randn(n, cout, h, w, generator=g))
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "GN_FUSED_STATS", fused)
+        xd = cl_bf16(x).requires_grad_(True)
+        wd = wt.to(DEV).requires_grad_(True)
+        gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+        y = ops.conv3x3(xd, wd, b.to(DEV), cl_bf16(r) if res else None, gn_stats=True)
+        part = ops._gn_partials_of(y, 32)
+        assert (part is not None) == fused
+        if fused:
+            assert part.shape == (n, hip_lib.odvae_conv_bf16_stats_chunks(h, w), 32, 2)
+            yc = y.detach().float().double().cpu().reshape(n, 32, cout // 32, h * w)
+            want = torch.stack([yc.sum(dim=(2, 3)), (yc * yc).sum(dim=(2, 3))], dim=-1)
+            got = part.double().cpu().sum(dim=1)
+            assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        z = ops.group_norm(y, gd, bd, 32, 1e-6, swish=True)
+        z.backward(gy)
+        outs.append((y.detach(), z.detach(), xd.grad, wd.grad, gd.grad, bd.grad))
+    assert torch.equal(outs[0][0], outs[1][0])                 # the conv output does not depend on the switch
+    for a, c, what, tol in zip(outs[0][1:], outs[1][1:], ("z", "dx", "dw", "dgamma", "dbeta"), (8e-3, 8e-3, 1e-3, 1e-3, 1e-3)):
+        # mean / rstd differ by f32 summation order only; z and dx are bf16 tensors: a last-place flip is 2^-8 of the value
+        assert (a.float() - c.float()).abs().max().item() <= tol * c.float().abs().max().item(), what
+    ref_y = rb(F.conv2d(x, wt, b, padding=1) + (r if res else 0.0))
+    ref_z = F.silu(F.group_norm(ref_y, 32, gamma, beta, eps=1e-6))
+    close(outs[0][1], ref_z, 2e-2, "conv -> GroupNorm(statistics from the epilogue) + swish vs torch")
