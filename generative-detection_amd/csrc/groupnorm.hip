@@ -427,8 +427,11 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gn_bwd_fused_kernel(GnFusedPara
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rs[h][j] * (dv[j] * gg[h][j] - (ds2[j] + xv[j] * ds1[j])) + kv[j];
+        // (the slot offset rides in the VECTOR offset here, not in soffset: LLVM's hazard recogniser skips the "VMEM store of more than
+        // 64 bits followed by a VALU write of its data registers" wait states when soffset is a register, and on gfx950 the hazard is
+        // real -- with `..., voff, i * step` the second dword of lanes 12-15 of every 16 carried the NEXT slot's value)
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])},
-                                               os, voff_of(i), i * step, 0);
+                                               os, voff_of(i) + (unsigned)(i * step), 0, 0);
       }
       if (more) {
 #pragma unroll
