@@ -1,7 +1,13 @@
 """Whole-path parity: PoseAutoencoder training step on the HIP kernels vs the CPU oracle (oracle/autoencoder.py),
-same weights, same batch, same injected noise.  Width-reduced network (ch=32) at 64x64, B=2, rec+KL only.
-Stated fp32 tolerances: latent z / reconstruction / losses 1e-3 relative to max|ref|; gradients 5e-3 (measured
-against max(|ref grad|, 1e-3 * largest gradient)); 3-step loss curve 2e-3."""
+same weights, same batch, same injected noise.  Width-reduced network (ch=32) at 64x64 and the benchmark's own network (ch=128) at
+256x256, B=2, rec+KL only.
+Stated fp32 tolerances = at most 4x what the path was MEASURED to use (tools/parity_margins.py -> profiles/r04_parity_margins.json;
+deviations relative to max|ref|, gradients to max(|ref grad|, 1e-3 * largest gradient)):
+  ch=32 @64x64 (no layer wide enough for F(4x4)):  outputs / loss terms 2e-5 (measured 4.9e-6), gradients 4.4e-4 (1.1e-4: a conv bias),
+  ch=128 @256x256, Winograd F(4x4,3x3) (default):  outputs / loss terms 8e-5 (1.9e-5), gradients 4.6e-3 (1.14e-3: post_quant_conv.weight,
+      a 16x16 matrix whose gradient sums the decoder's dz over every pixel; decoder 8.8e-4, encoder 2.8e-5),
+  the same on F(2x2,3x3) (ODVAE_CONV_WINOGRAD4=0):  outputs 2.7e-5 (6.7e-6), gradients 4e-5 (9.6e-6),
+  3-step loss curves 4e-6 (9e-7); weights after 3 Adam steps use 0.03-0.10 of their bound (2.2 lr per step + 5e-3 max|w|)."""
 import os
 
 import pytest
@@ -47,18 +53,20 @@ def test_training_step_matches_oracle(hip_lib, global_step):
     """global_step 1: every loss term (the rec / KL terms join when step > encoder_pretrain_steps, contperceptual.py:307);
     global_step 0: the pose-only total of the very first step."""
     model, ref = build_pair()
-    check_step(model, ref, global_step, height=64, latent_hw=4)
+    check_step(model, ref, global_step, height=64, latent_hw=4, tol_out=2e-5, tol_grad=4.4e-4)
 
 
 def test_training_step_at_headline_shapes_matches_oracle(hip_lib):
     """The benchmark's own network and resolution (ch=128, 256x256, z = 16x16x16; B=2 so that the oracle finishes in
     seconds): every kernel runs at the channel counts, tile counts and 4 096 attention tokens of BASELINE.json configs[1],
     through the Winograd, parity-class upsample and thin-side paths the width-reduced tests only touch in part."""
+    from odvae_amd import ops
     model, ref = build_pair(latent_hw=16, ch=None)
-    check_step(model, ref, 1, height=256, latent_hw=16)
+    f4 = ops.WINOGRAD and ops.WINOGRAD4
+    check_step(model, ref, 1, height=256, latent_hw=16, tol_out=8e-5 if f4 else 2.7e-5, tol_grad=4.6e-3 if f4 else 4e-5)
 
 
-def check_step(model, ref, global_step, height, latent_hw):
+def check_step(model, ref, global_step, height, latent_hw, tol_out=1e-3, tol_grad=5e-3):
     from odvae_amd import synthetic
     model.train(); ref.train()
     model.loss.log_exact_g_loss = True
@@ -69,15 +77,15 @@ def check_step(model, ref, global_step, height, latent_hw):
     loss = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0, 0)
     loss_ref, log_ref, aux = ref.training_step(batch, 0, noise)
     logs = model.logged_metrics
-    assert rel(loss, loss_ref) < 1e-3, (loss.item(), loss_ref.item())
+    assert rel(loss, loss_ref) < tol_out, (loss.item(), loss_ref.item())
     for key in ("kl_loss_obj", "nll_loss", "rec_loss", "pose_loss", "class_loss", "bbox_loss", "kl_loss_bbox", "fill_factor_loss",
                 "g_loss"):   # g_loss with the discriminator off: -mean D(x_rec), evaluated without a graph (contperceptual.py:285-292)
-        assert rel(logs["train/" + key], log_ref["train/" + key]) < 1e-3, key
+        assert rel(logs["train/" + key], log_ref["train/" + key]) < tol_out, (key, rel(logs["train/" + key], log_ref["train/" + key]))
     # latent / reconstruction
     dec_obj, dec_pose, post, _ = model.forward(model._rescale(batch["patch"].to("cuda:0")))
-    assert rel(post.parameters, aux["posterior"].parameters) < 1e-3
-    assert rel(dec_obj, aux["dec_obj"]) < 1e-3
-    assert rel(dec_pose, aux["dec_pose"]) < 1e-3
+    assert rel(post.parameters, aux["posterior"].parameters) < tol_out
+    assert rel(dec_obj, aux["dec_obj"]) < tol_out
+    assert rel(dec_pose, aux["dec_pose"]) < tol_out
     loss.backward()
     loss_ref.backward()
     ref_params = dict(ref.named_parameters())
@@ -96,7 +104,7 @@ def check_step(model, ref, global_step, height, latent_hw):
         e = (p.grad.detach().cpu().double() - rg.double()).abs().max().item() / max(rg.abs().max().item(), 1e-3 * scale)
         if e > worst[1]:
             worst = (name, e)
-    assert worst[1] < 5e-3, "param grad %s rel err %.3e" % worst
+    assert worst[1] < tol_grad, "param grad %s rel err %.3e" % worst
     if global_step > 0:   # the reconstruction terms reach the decoder and, through z, the encoder
         assert {"encoder", "decoder", "quant_conv_obj", "post_quant_conv"} <= compared, compared
         assert ref_params["decoder.conv_in.weight"].grad.abs().max().item() > 0
@@ -166,7 +174,7 @@ def test_three_step_loss_curve_matches_oracle(hip_lib, ch, height, latent_hw):
         out = train_batch(ref, ref_opts, batch, {0: noise}, optimizer_indices=(0,), clip=1.0)
         curve.append(losses[0].item()); curve_ref.append(out[0][0].item())
     for a, b in zip(curve, curve_ref):
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (curve, curve_ref)
+        assert abs(a - b) <= 4e-6 * max(1.0, abs(b)), (curve, curve_ref)      # measured 1.5e-7 / 9e-7 (profiles/r04_parity_margins.json)
     assert model.global_step == 3 and ref.global_step == 3
     # weights after three Adam steps
     ref_sd = ref.state_dict()
