@@ -539,9 +539,10 @@ def main():
                     fam = os.path.join(ROOT, "profiles", "r04_family_traffic.json")
                     if not (args.gan or args.bf16 or args.ckpt_decoder) and args.res == 256 and args.batch == 32 and os.path.exists(fam):
                         # HBM bytes the family actually moves (statistics / reduce are passes of their own), from the committed PMC
-                        # passes of this command (FETCH_SIZE x2 + WRITE_SIZE, two steps counted), over the time measured live here
-                        ks = json.load(open(fam))["kernels"]
-                        moved = sum((v["fetch_bytes_total_corrected"] + v["write_bytes_total"]) / 2.0 for k, v in ks.items() if k.startswith("gn_"))
+                        # passes of this command (FETCH_SIZE x2 + WRITE_SIZE over `steps_counted` steps), over the time measured live here
+                        fj = json.load(open(fam))
+                        ks, nsteps = fj["kernels"], float(fj["steps_counted"])
+                        moved = sum((v["fetch_bytes_total_corrected"] + v["write_bytes_total"]) / nsteps for k, v in ks.items() if k.startswith("gn_"))
                         e.update({"traffic": moved, "traffic_unit": "HBM bytes per step (PMC, profiles/r04_family_traffic.json)",
                                   "achieved_on_traffic": moved / (e["total_ms"] * 1e-3) / 1e9,
                                   "frac_on_traffic": moved / (e["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS})

@@ -33,9 +33,11 @@ for k in kernels:
               "hbm_bytes_per_launch": (fb + wb) / len(fv),
               "duration_ms_total_under_counters": sum(dv) / 1e6 if dv else None,
               "hbm_TB_per_s": (fb + wb) / (sum(dv) * 1e-9) / 1e12 if dv else None}
-json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 (both steps counted); "
-                     "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; durations from the FETCH_SIZE pass",
-           "kernels": res}, open(out, "w"), indent=1)
+steps = sum(len(v) for name, v in dur.items() if "adam_kernel" in name)      # one Adam launch per training step of this configuration
+json.dump({"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 "
+                     "--no-kernel-events (warm-up + timed + the three host-enqueue steps: every step of the process is counted, "
+                     "steps_counted = launches of adam_kernel); FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; durations from the FETCH_SIZE pass",
+           "steps_counted": steps, "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf /tmp/pmc_fam_FETCH_SIZE /tmp/pmc_fam_WRITE_SIZE
