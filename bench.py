@@ -177,6 +177,33 @@ def alloc_counters(dev):
     return d
 
 
+class GcWatch:
+    """Python garbage collections inside a timed region: count and host milliseconds per generation (a full, generation-2 collection of
+    this process's ~10^5 objects stalls the host for tens of milliseconds; whether one coincides with a slow step is in the record)."""
+
+    def __init__(self):
+        self.log, self._t0 = [], 0.0
+
+    def _cb(self, phase, info):
+        if phase == "start":
+            self._t0 = time.perf_counter()
+        else:
+            self.log.append((info["generation"], (time.perf_counter() - self._t0) * 1e3))
+
+    def __enter__(self):
+        import gc
+        gc.callbacks.append(self._cb)
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        gc.callbacks.remove(self._cb)
+
+    def summary(self):
+        return {"gen%d" % g: {"collections": sum(1 for gg, _ in self.log if gg == g), "host_ms": round(sum(t for gg, t in self.log if gg == g), 2),
+                              "longest_ms": round(max([t for gg, t in self.log if gg == g] or [0.0]), 2)} for g in (0, 1, 2)}
+
+
 def timed_loop(step, first_index, steps, dev):
     """K steps with one HIP event in front of each and one behind the last, on the stream the kernels are launched on: wall time
     (host clock, device-synchronised at both ends), the GPU-side elapsed time of the same loop, per-step GPU times, the host's enqueue
@@ -185,20 +212,22 @@ def timed_loop(step, first_index, steps, dev):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     state0, a0 = gpu_state(dev), alloc_counters(dev)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ev[i].record()
-        step(first_index + i)
-    ev[steps].record()
-    host = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    with GcWatch() as gcw:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i].record()
+            step(first_index + i)
+        ev[steps].record()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
     state1, a1 = gpu_state(dev), alloc_counters(dev)
     per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     diag = {"gpu_elapsed_ms_per_step": ev[0].elapsed_time(ev[steps]) / steps,
             "gpu_step_ms": {"min": per[0], "median": per[len(per) // 2], "max": per[-1],
                             "all": [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(steps)] if steps <= 64 else None},
             "allocator_delta": {k: a1[k] - a0[k] for k in _ALLOC_KEYS},
+            "python_gc_in_timed_loop": gcw.summary(),
             "allocator_after": {"reserved_gb": a1["reserved_gb"], "allocated_gb": a1["allocated_gb"]},
             "gpu_state_before": state0, "gpu_state_after": state1}
     return wall, host, diag
@@ -406,6 +435,7 @@ def main():
     sample = 8 if (args.bf16 and not args.no_kernel_events) else 1   # launches / share below are scaled back by it (estimates when > 1)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one per step boundary, on the launch stream
     state0, alloc0 = gpu_state(dev), alloc_counters(dev)
+    gcw = GcWatch().__enter__()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step_ev[i].record()
@@ -417,6 +447,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gcw.__exit__()
     state1, alloc1 = gpu_state(dev), alloc_counters(dev)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -465,6 +496,7 @@ def main():
                                          "all": [round(v, 3) for v in per] if len(per) <= 64 else None})(
                 [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]),
             "allocator_delta": {k: alloc1[k] - alloc0[k] for k in _ALLOC_KEYS},
+            "python_gc_in_timed_loop": gcw.summary(),
             "gpu_state_before": state0, "gpu_state_after": state1,
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
                        % (args.res, args.res, args.batch,

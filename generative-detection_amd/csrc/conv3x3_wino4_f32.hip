@@ -51,6 +51,8 @@ struct Wino4Params {
   float* y;               // [N][H][W][Cout]
   int N, H, W, Cin, Cout, CinP, CoutP, tiles_x, tiles_y, act, xcd;
   int persist;            // 1: 1-D grid of one block per CU, every block walks a sequence of tiles of one output-channel block
+  int up;                 // 1: x is the LOW-resolution input [N][H/2][W/2][Cin] of an Upsample conv (nearest 2x + 3x3): the halo of the
+                          // upsampled image is fetched from x[iy >> 1][ix >> 1]; H, W are the OUTPUT's
   float* gn_partial;      // [N][tiles per image][gn_groups][2] (sum, sum of squares of y per tile and channel group) or null
   int gn_groups, gn_cpg;  // channel groups of the GroupNorm that reads y, channels per group (a power of two <= 32)
 };
@@ -82,7 +84,8 @@ __device__ __forceinline__ void column_pass_store(const f32x2 (&t)[6], unsigned 
 // STATS: the output transform also leaves the GroupNorm statistics of y (p.gn_partial).  A template parameter, not a run-time branch: the
 // two accumulators and the exchange live only in the instantiation the statistics launches use, so the data-gradient launches and every
 // launch without a GroupNorm consumer run the plain build (255 registers, no scratch).
-template <bool STATS>
+// UP: the Upsample form (x at half resolution, Wino4Params::up), likewise compiled in only where it is launched.
+template <bool STATS, bool UP>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   extern __shared__ __attribute__((aligned(16))) float dsmem[];
   const unsigned lds0 = lds_addr_of(dsmem);
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   i32x4_t xrs;
   unsigned hvoff[HALO_DMA_PER_WAVE];
   auto set_halo = [&](const Tile& T) {
-    xrs = rsrc_words(p.x + (int64_t)T.n * p.H * p.W * p.Cin, (unsigned)(p.H * p.W * p.Cin) * 4u);
+    const int xh = UP ? p.H >> 1 : p.H, xw = UP ? p.W >> 1 : p.W;      // rows / columns of x in memory
+    xrs = rsrc_words(p.x + (int64_t)T.n * xh * xw * p.Cin, (unsigned)(xh * xw * p.Cin) * 4u);
     // (the slot -> (plane, row, x) arithmetic depends on the lane only; from an opaque copy of the lane id it is redone per tile --
     // a dozen integer operations -- instead of being hoisted out of the tile loop and parked in scratch across the main loop)
     int lane_h = lane;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       const int hx = 4 * (xp % 9) + xp / 9;
       const int iy = T.oy0 - 1 + hr, ix = T.ox0 - 1 + hx;
       const bool ok = s < HALO_SLOTS && xp < 36 && hx < TW + 2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      hvoff[k] = ok ? (unsigned)(((iy * p.W + ix) * p.Cin + 4 * quad) * 4) : OOB;
+      hvoff[k] = ok ? (unsigned)((((UP ? iy >> 1 : iy) * xw + (UP ? ix >> 1 : ix)) * p.Cin + 4 * quad) * 4) : OOB;
     }
   };
   set_halo(cur);
@@ -498,7 +502,7 @@ int odvae_conv3x3_pack_wino4_f32(const float* w, int Cout, int Cin, float* fwd_p
 int odvae_conv3x3_wino4_stats_chunks(int H, int W) { return ceil_div(H, TH) * ceil_div(W, TW); }
 
 static int wino4_launch(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
-                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream);
+                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream, int up = 0);
 
 // y = conv3x3_stride1_pad1(x) (+bias) (+residual); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino4_f32; act must be 0
 // (a fused ReLU is not offered: ops.py keeps the ReLU convs of the VGG stack on F(2x2) for accuracy, see there).
@@ -519,8 +523,23 @@ int odvae_conv3x3_wino4_stats_f32(const float* x, int N, int H, int W, int Cin, 
   return wino4_launch(x, N, H, W, Cin, upk, Cout, bias, residual, y, 0, gn_partial, gn_groups, stream);
 }
 
+// Upsample conv ([UPSTREAM] Upsample.forward: F.interpolate(scale 2, nearest) then conv3x3) on the same kernel: x is the low-resolution
+// input [N][H/2][W/2][Cin], y [N][H][W][Cout]; the 4x intermediate is never formed -- the halo DMA reads x[iy >> 1][ix >> 1].  2.25
+// multiply-adds per output pixel and (ci, co) against the 4 of the parity-class kernels (conv3x3_f32.hip mode 5).  gn_partial /
+// gn_groups as in odvae_conv3x3_wino4_stats_f32, or NULL / 0.
+int odvae_conv3x3_wino4_up_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
+                               const float* bias, const float* residual, float* y, float* gn_partial, int gn_groups, void* stream) {
+  ODVAE_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv3x3_wino4_up: output %dx%d is not twice an input size", H, W);
+  if (gn_partial) {
+    ODVAE_CHECK_ARG(gn_groups > 0 && Cout % gn_groups == 0, "conv3x3_wino4_up: bad statistics arguments");
+    const int cpg = Cout / gn_groups;
+    ODVAE_CHECK_ARG(cpg <= 32 && (cpg & (cpg - 1)) == 0, "conv3x3_wino4_up: %d channels per group (needs a power of two <= 32)", cpg);
+  }
+  return wino4_launch(x, N, H, W, Cin, upk, Cout, bias, residual, y, 0, gn_partial, gn_partial ? gn_groups : 0, stream, 1);
+}
+
 static int wino4_launch(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
-                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream) {
+                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream, int up) {
   ODVAE_CHECK_ARG(x && upk && y, "conv3x3_wino4: null operand");
   ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino4: empty shape");
   ODVAE_CHECK_ARG(act == 0, "conv3x3_wino4: no fused activation (act=%d); ReLU convs stay on odvae_conv3x3_wino_f32", act);
@@ -534,12 +553,14 @@ static int wino4_launch(const float* x, int N, int H, int W, int Cin, const floa
   p.CinP = odvae_conv3x3_wino4_reduce_pad(Cin); p.CoutP = odvae_conv3x3_wino4_out_pad(Cout);
   p.tiles_x = ceil_div(W, TW); p.tiles_y = ceil_div(H, TH); p.act = act;
   p.gn_partial = gn_partial; p.gn_groups = gn_groups; p.gn_cpg = gn_groups > 0 ? Cout / gn_groups : 0;
+  p.up = up;
   ODVAE_CHECK_ARG((int64_t)36 * p.CinP * p.CoutP * 4 < 0x7FFFFFF0ll, "conv3x3_wino4: pack too large");
   const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino4: too many tiles");
   static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
   p.xcd = xcd ? 1 : 0;
-  const auto kern = gn_partial ? conv3x3_wino4_kernel<true> : conv3x3_wino4_kernel<false>;
+  const auto kern = up ? (gn_partial ? conv3x3_wino4_kernel<true, true> : conv3x3_wino4_kernel<false, true>)
+                       : (gn_partial ? conv3x3_wino4_kernel<true, false> : conv3x3_wino4_kernel<false, false>);
   const unsigned lds_bytes = gn_partial ? LDS_B + STATS_B : LDS_B;
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) {

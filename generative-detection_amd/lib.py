@@ -44,6 +44,7 @@ PROTOTYPES = {
     "odvae_conv3x3_wino4_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "odvae_conv3x3_wino4_stats_chunks": (_I, [_I, _I]),
     "odvae_conv3x3_wino4_stats_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "odvae_conv3x3_wino4_up_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),

@@ -59,7 +59,8 @@ class Upsample(nn.Module):
         self.conv = Conv3x3(channels, channels, mode=2)
 
     def forward(self, x):
-        return self.conv(x)  # nearest 2x is folded into the conv's input gather
+        # nearest 2x is folded into the conv's input gather; a ResnetBlock's norm1 reads the result: statistics from the conv's epilogue
+        return self.conv(x, gn_stats=True)
 
 
 class Downsample(nn.Module):

@@ -199,6 +199,9 @@ def pack_conv3x3(weight, want_fwd=True, want_dgrad=False, up=False):
 # Upsample + conv3x3: 1 = per output parity class with pre-summed taps (modes 5 / 6, 16 instead of 36 tap-products per
 # input pixel); ODVAE_UPCONV_DENSE=1 keeps the dense form (mode 2, data gradient = mode 0 + 2x2 sum-pool) for A/B runs
 UPCONV_BY_PARITY = os.environ.get("ODVAE_UPCONV_DENSE", "0") != "1"
+# Upsample conv forward / data gradient on the F(4x4,3x3) kernel where the OUTPUT shape qualifies (2.25 instead of 4 multiply-adds per output
+# pixel; the weight gradient stays on the parity-class kernel); ODVAE_UPCONV_WINOGRAD4=0 keeps modes 5 / 6
+UPCONV_WINOGRAD4 = os.environ.get("ODVAE_UPCONV_WINOGRAD4", "1") != "0"
 
 
 def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
@@ -264,14 +267,22 @@ def _gn_stats_ok(cout):
     return GN_FUSED_STATS and cout % GN_GROUPS == 0 and 1 <= cpg <= 32 and (cpg & (cpg - 1)) == 0
 
 
-def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False, stats=False):
-    """stats=True (F(4x4) only): returns (y, partials [N][tiles][32][2]) -- the GroupNorm statistics of y per output tile."""
+def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False, stats=False, up=False):
+    """stats=True (F(4x4) only): returns (y, partials [N][tiles][32][2]) -- the GroupNorm statistics of y per output tile.
+    up=True (F(4x4) only): x is the low-resolution input of an Upsample conv, y has twice its height and width."""
     L = _L()
     n, _, h, w = x.shape
+    if up:
+        h, w = 2 * h, 2 * w
     y = _new_cl(n, cout, h, w, x)
     tag = KERNEL_EVENTS.begin() if cout > 32 else None
     partial = None
-    if stats:
+    if up:
+        if stats:
+            partial = torch.empty(n, L.odvae_conv3x3_wino4_stats_chunks(h, w), GN_GROUPS, 2, dtype=torch.float32, device=x.device)
+        _lib.check(L.odvae_conv3x3_wino4_up_f32(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
+                                                y.data_ptr(), _lib.ptr(partial), GN_GROUPS if stats else 0, _lib.stream_ptr()), "conv3x3_wino4_up")
+    elif stats:
         partial = torch.empty(n, L.odvae_conv3x3_wino4_stats_chunks(h, w), GN_GROUPS, 2, dtype=torch.float32, device=x.device)
         _lib.check(L.odvae_conv3x3_wino4_stats_f32(x.data_ptr(), n, h, w, cin, pack.data_ptr(), cout, _lib.ptr(bias), _lib.ptr(residual),
                                                    y.data_ptr(), partial.data_ptr(), GN_GROUPS, _lib.stream_ptr()), "conv3x3_wino4_stats")
@@ -281,7 +292,7 @@ def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False, stats
                       y.data_ptr(), int(act), _lib.stream_ptr()), "conv3x3_wino4" if f4 else "conv3x3_wino")
     # issued multiply-adds per output pixel and (ci, co): F(2x2,3x3) 16 per 2x2 tile = 4, F(4x4,3x3) 36 per 4x4 tile = 2.25
     KERNEL_EVENTS.end("conv3x3_wino4" if f4 else "conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
-                      4.0 * (n * h * w * cin + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
+                      4.0 * (n * h * w * cin // (4 if up else 1) + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
                       issued=2.0 * (2.25 if f4 else 4.0) * cin * cout * n * h * w)
     return (y, partial) if stats else y
 
@@ -297,14 +308,21 @@ class _Conv3x3(Function):
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
         up = mode == 2 and UPCONV_BY_PARITY
+        if up and UPCONV_WINOGRAD4 and not relu and _wino4_ok(2 * x.shape[2], 2 * x.shape[3], cin, cout):
+            # the Upsample conv on the F(4x4) kernel: the halo of the (never formed) upsampled image is read from x[iy >> 1][ix >> 1]
+            up = "wino4up"
         if mode == 0 and _wino_ok(x.shape[2], x.shape[3], cin, cout):
             # (not with a fused ReLU, i.e. not in the frozen VGG stack of the perceptual loss: F(4x4)'s ~1e-5 output error flips ten times
             # more ReLU masks than F(2x2)'s ~1e-6, and the input gradient of LPIPS then leaves the 5e-3 the parity tests hold it to)
             up = "wino4" if (not relu and _wino4_ok(x.shape[2], x.shape[3], cin, cout)) else "wino"
-        fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), up)  # both packs in one launch
+        fwd_pack, _ = pack_conv3x3(weight, True, bool(ctx.needs_input_grad[0]), "wino4" if up == "wino4up" else up)  # both packs in one launch
         b = bias.detach().contiguous() if bias is not None else None
         partial = None
-        if up == "wino4" and gn_stats and _gn_stats_ok(cout):
+        if up == "wino4up":
+            want = bool(gn_stats and _gn_stats_ok(cout))
+            out = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, f4=True, stats=want, up=True)
+            y, partial = out if want else (out, None)
+        elif up == "wino4" and gn_stats and _gn_stats_ok(cout):
             y, partial = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, f4=True, stats=True)
         elif up in ("wino", "wino4"):
             y = _conv3x3_wino_raw(x, fwd_pack, cin, cout, b, res, act=1 if relu else 0, f4=up == "wino4")
@@ -339,8 +357,12 @@ class _Conv3x3(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             PACK_CACHE.check_epoch(ctx.pack_epoch, "conv3x3 backward")
-            _, dgr = pack_conv3x3(weight, False, True, ctx.up)
-            if ctx.up in ("wino", "wino4"):
+            _, dgr = pack_conv3x3(weight, False, True, "wino4" if ctx.up == "wino4up" else ctx.up)
+            if ctx.up == "wino4up":     # gradient w.r.t. the upsampled image on the F(4x4) kernel, then its 2x2 sum-pool
+                du = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=True)
+                dx = _new_cl(n, cin, hi, wi, x)
+                _lib.check(L.odvae_upsample2x_bwd_f32(du.data_ptr(), dx.data_ptr(), n, hi, wi, cin, _lib.stream_ptr()), "upsample2x_bwd")
+            elif ctx.up in ("wino", "wino4"):
                 dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=ctx.up == "wino4")
             elif mode == 0:
                 dx = _conv3x3_raw(0, dy, dgr, cout, cin, None, None)
@@ -356,7 +378,7 @@ class _Conv3x3(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            wmode = 5 if ctx.up is True else mode
+            wmode = 5 if ctx.up in (True, "wino4up") else mode
             if mode == 0 and WGRAD_WINOGRAD and L.odvae_conv3x3_wgrad_wino_supported(n, hi, wi, cin, cout):
                 need = L.odvae_conv3x3_wgrad_wino_workspace_bytes(n, hi, wi, cin, cout)
                 wp, wn = _ws(need, x)
@@ -394,7 +416,7 @@ def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=Fal
                 y._gn_partials = (partial, y.data_ptr(), y._version, tuple(y.shape))
             return y
         return _ConvB.apply(x, weight, bias, residual, mode, bool(out_f32))
-    if gn_stats and not relu and mode == 0:
+    if gn_stats and not relu and mode in (0, 2):
         y, partial = _Conv3x3.apply(x, weight, bias, residual, mode, relu, True)
         if partial is not None:
             # the statistics are valid for exactly these values: the tag (storage, version counter, shape) lets the consumer tell

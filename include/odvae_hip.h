@@ -108,6 +108,11 @@ int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const 
 int odvae_conv3x3_wino4_stats_chunks(int H, int W);
 int odvae_conv3x3_wino4_stats_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
                                   const float* bias, const float* residual, float* y, float* gn_partial, int gn_groups, void* stream);
+/* The Upsample conv (nearest 2x, then 3x3 stride 1 pad 1) on the same kernel: x [N][H/2][W/2][Cin] low resolution, y [N][H][W][Cout];
+ * upk = the forward pack of odvae_conv3x3_pack_wino4_f32; gn_partial / gn_groups as above or NULL / 0.  Shapes:
+ * odvae_conv3x3_wino4_supported(H, W, Cin, Cout) on the OUTPUT size. */
+int odvae_conv3x3_wino4_up_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout, const float* bias,
+                               const float* residual, float* y, float* gn_partial, int gn_groups, void* stream);
 
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
  * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)

@@ -605,3 +605,36 @@ def test_fails_loudly_on_cpu_tensor(hip_lib):
     from odvae_amd import ops, lib
     with pytest.raises(lib.HipLibraryError):
         ops.group_norm(torch.randn(1, 32, 4, 4), torch.ones(32), torch.zeros(32), 32, 1e-6, True)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 8, 16), (1, 128, 128, 18, 34), (2, 256, 128, 16, 16), (8, 128, 128, 64, 64)])
+def test_upsample_conv_on_the_f4x4_kernel(hip_lib, monkeypatch, n, cin, cout, h, w):
+    """[UPSTREAM] Upsample.forward (nearest 2x, then conv3x3) with the forward and the data gradient on the Winograd F(4x4,3x3) kernel
+    (`odvae_conv3x3_wino4_up_f32`: the halo of the never-formed upsampled image is read from x[iy >> 1][ix >> 1]) against torch on the
+    host and against the parity-class kernels (modes 5 / 6); the output's GroupNorm statistics come from the same epilogue.
+    Shapes: one tile, ragged tiles in both directions, Cin != Cout, the persistent form."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(n + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    gy = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, br, padding=1)
+    y_ref.backward(gy)
+    outs = {}
+    for f4 in (True, False):
+        monkeypatch.setattr(ops, "UPCONV_WINOGRAD4", f4)
+        xd, wd, bd = x.to(dev()).requires_grad_(True), wt.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+        y = ops.conv3x3(xd, wd, bd, None, mode=2, gn_stats=True)
+        part = ops._gn_partials_of(y, 32)
+        assert (part is not None) == (f4 and cout % 32 == 0)
+        if part is not None:
+            yc = y.detach().double().cpu().reshape(n, 32, cout // 32, 4 * h * w)
+            want = torch.stack([yc.sum(dim=(2, 3)), (yc * yc).sum(dim=(2, 3))], dim=-1)
+            assert (part.double().cpu().sum(dim=1) - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        y.backward(gy.to(dev()))
+        outs[f4] = (y.detach(), xd.grad, wd.grad, bd.grad)
+    for (a, c, ref, what) in zip(outs[True], outs[False], (y_ref, xr.grad, wr.grad, br.grad), ("y", "dx", "dw", "db")):
+        close(a, ref, 5e-4 if what in ("y", "dx") else BWD_TOL * 4, "upsample conv on F(4x4): " + what)
+        assert (a - c).abs().max().item() <= 6e-5 * max(1.0, c.abs().max().item()), what + " vs the parity-class kernels"
