@@ -509,8 +509,7 @@ def main():
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
             tfile = None
-            for cand in (("r04_bf16_conv_traffic.json", "r03_bf16_conv_traffic.json") if args.bf16
-                         else ("r04_conv3x3_traffic.json", "r03_conv3x3_traffic.json")):
+            for cand in (("r04_bf16_conv_traffic.json",) if args.bf16 else ("r04_conv3x3_traffic.json",)):   # this round's PMC passes only
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     tfile = cand
                     break
