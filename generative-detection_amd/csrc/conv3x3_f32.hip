@@ -640,6 +640,78 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_in_kernel(ConvParams p) {
   }
 }
 
+// ---- thin output: at most 3 channels out (decoder.conv_out, 128 -> 3: the reconstruction) ---------------------------------
+// The implicit-GEMM kernel pads the output channels to 32: 10x wasted MFMA work (1.29 ms per step).  Here the nine taps of the three
+// output channels form ONE 32-wide MFMA operand instead: Y27[px][tap * 3 + co] = sum_ci x[px][ci] w[co][ci][tap] is a 1x1 product
+// over the tile's pixels INCLUDING its halo ring (27 of 32 columns useful, K = Cin), kept in LDS, and an output pixel is the sum of
+// nine of its entries, one per tap, each taken at that tap's neighbour: y[p][co] = b[co] + sum_tap Y27[p + off(tap)][3 tap + co].
+// Block = 8 x 32 output pixels; Y27 for the 10 x 34 halo region = eleven 32-pixel MFMA row tiles shared by four waves; the weight
+// matrix W27 [Cin][32] sits in Cin / 2 registers per lane.  Out-of-image halo pixels read as zeros, so their Y27 rows are zero: the
+// conv's zero padding.  No activation, no residual (conv_out has neither).
+constexpr int TO_TH = 8, TO_TW = 32, TO_HW = TO_TW + 2, TO_HPIX = (TO_TH + 2) * TO_HW, TO_MT = (TO_HPIX + 31) / 32;
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_thin_out_kernel(ConvParams p) {
+  __shared__ float Y[TO_MT * 32][32 + 1];     // [halo pixel][tap * 3 + co], +1: the nine-term gather walks rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kk = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y; const int n = t / p.tiles_y;
+  const int oy0 = ty * TO_TH, ox0 = tx * TO_TW;
+  const int QT = p.CinP / 4;
+  // B operand: lane (column nn = li, k parity kk) holds W27[2 s + kk][nn] for s = 0 .. CIN/2 - 1
+  float bw[CIN / 2];
+  {
+    const int tap = li / 3, co = li - 3 * tap;
+#pragma unroll
+    for (int s = 0; s < CIN / 2; ++s) {
+      const int ci = 2 * s + kk;
+      bw[s] = (li < 27 && co < p.Cout) ? p.wpk[(((int64_t)tap * QT + (ci >> 2)) * p.CoutP + co) * 4 + (ci & 3)] : 0.f;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (int64_t)n * p.Hi * p.Wi * p.Cin, 0,
+                                                                       p.Hi * p.Wi * p.Cin * 4, 0x00020000);
+  for (int mt = wave; mt < TO_MT; mt += 4) {
+    const int hp = mt * 32 + li;                         // halo pixel of this lane's MFMA row
+    const int hy = hp / TO_HW, hx = hp - hy * TO_HW;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    const bool ok = hp < TO_HPIX && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+    const unsigned voff = ok ? (unsigned)((iy * p.Wi + ix) * p.Cin) * 4u : 0x7FFFFFF0u;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < CIN / 4; c4 += 4) {            // four 16-byte loads in flight: channels 4 c4 .. 4 c4 + 15 of the lane's pixel
+      u32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, (c4 + j) * 16, 0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // k-step s of this lane is channel 2 s + kk: of channels 4q .. 4q+3 the lane takes q*4 + kk (s = 2q) and q*4 + 2 + kk (s = 2q + 1)
+        const float a0 = __uint_as_float(kk ? v[j].y : v[j].x), a1 = __uint_as_float(kk ? v[j].w : v[j].z);
+        acc = mfma32(a0, bw[2 * (c4 + j)], acc);
+        acc = mfma32(a1, bw[2 * (c4 + j) + 1], acc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Y[mt * 32 + acc_row(r, lane)][li] = acc[r];
+  }
+  __syncthreads();
+  // one output pixel per thread: nine taps x Cout values out of its 3 x 3 neighbourhood of Y27 rows
+  const int r = tid / TO_TW, c = tid - r * TO_TW;
+  const int oy = oy0 + r, ox = ox0 + c;
+  if (oy < p.Ho && ox < p.Wo) {
+    float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* row = Y[(r + tap / 3) * TO_HW + c + tap % 3];
+#pragma unroll
+      for (int co = 0; co < 3; ++co) o[co] += row[3 * tap + co];
+    }
+    float* dst = p.y + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout;
+    for (int co = 0; co < p.Cout; ++co) dst[co] = o[co] + (p.bias ? p.bias[co] : 0.f);
+  }
+}
+
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 }  // namespace
@@ -731,6 +803,14 @@ int odvae_conv3x3_f32(int mode, const float* x, int N, int Hi, int Wi, int Cin,
     const int blocks = (int)std::min<int64_t>(1024, ceil_div64(ntiles, 4));
     hipLaunchKernelGGL(conv3x3_thin_in_kernel, dim3(blocks, ceil_div(Cout, 128)), block, 0, st, p);
     ODVAE_LAUNCH_CHECK("conv3x3 thin-in");
+    return ODVAE_OK;
+  }
+  static const bool thin_out_off = getenv("ODVAE_CONV_THIN_OUT_OFF") != nullptr;
+  if (mode == 0 && Cout <= 3 && Cin == 128 && !residual && act == 0 && !thin_out_off) {      // decoder.conv_out: the reconstruction
+    p.tiles_x = ceil_div(Wo, TO_TW); p.tiles_y = ceil_div(Ho, TO_TH);
+    ODVAE_CHECK_ARG((int64_t)p.tiles_x * p.tiles_y * N < (1ll << 31), "conv3x3: too many tiles");
+    hipLaunchKernelGGL(conv3x3_thin_out_kernel<128>, dim3((unsigned)(p.tiles_x * p.tiles_y * N)), block, 0, st, p);
+    ODVAE_LAUNCH_CHECK("conv3x3 thin-out");
     return ODVAE_OK;
   }
   // ODVAE_CONV_VARIANT=0 selects the first per-tap-barrier kernel (kept for in-process A/B timing and as the

@@ -638,3 +638,28 @@ def test_upsample_conv_on_the_f4x4_kernel(hip_lib, monkeypatch, n, cin, cout, h,
     for (a, c, ref, what) in zip(outs[True], outs[False], (y_ref, xr.grad, wr.grad, br.grad), ("y", "dx", "dw", "db")):
         close(a, ref, 5e-4 if what in ("y", "dx") else BWD_TOL * 4, "upsample conv on F(4x4): " + what)
         assert (a - c).abs().max().item() <= 6e-5 * max(1.0, c.abs().max().item()), what + " vs the parity-class kernels"
+
+
+@pytest.mark.parametrize("n,cout,h,w", [(2, 3, 16, 32), (1, 3, 20, 36), (3, 2, 8, 8), (2, 3, 64, 96), (1, 1, 9, 33)])
+def test_thin_output_conv(hip_lib, n, cout, h, w):
+    """decoder.conv_out (128 -> 3, [UPSTREAM] Decoder.forward) on `conv3x3_thin_out_kernel`: the nine taps of the output channels as one
+    32-wide MFMA operand over the tile and its halo ring, then a nine-term gather -- forward against torch on the host (whole and
+    ragged tiles, image borders inside a tile, 1-3 output channels); the backward of this layer runs the thin-side kernels tested above."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(n + cout + h)
+    x = torch.randn(n, 128, h, w, generator=g)
+    wt = torch.randn(cout, 128, 3, 3, generator=g) / math.sqrt(9 * 128)
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, padding=1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd, wd, bd = x.to(dev()).requires_grad_(True), wt.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.conv3x3(xd, wd, bd)
+    close(y, y_ref, FWD_TOL, "thin-output conv forward")
+    y.backward(gy.to(dev()))
+    close(xd.grad, xr.grad, BWD_TOL, "dx")
+    close(wd.grad, wr.grad, BWD_TOL * 4, "dw")
+    close(bd.grad, br.grad, BWD_TOL * 4, "db")
+    # without a bias
+    close(ops.conv3x3(xd.detach(), wd.detach(), None), F.conv2d(x, wt, None, padding=1), FWD_TOL, "thin-output conv, no bias")
