@@ -17,6 +17,14 @@ import os
 import sys
 import time
 
+# Host threads: the step's host side is one Python thread issuing launches plus a few tiny CPU tensor ops (the reference draws its noise on the
+# CPU).  Left alone, torch sizes its intra-op pool by the machine (hundreds of hardware threads on a GPU host) and OpenMP workers SPIN after
+# each parallel region; inside a container with a CPU quota that burns the quota and the kernel throttles the whole cgroup until the next
+# 100 ms period -- seen as single steps with 100-200 ms of host enqueue time (`host_enqueue_ms_by_step`, `cgroup_cpu`) in otherwise flat
+# runs.  Passive waiting must be set before the OpenMP runtime loads; the pool size is set in main().
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -166,6 +174,19 @@ def gpu_state(dev):
     return out
 
 
+def cgroup_cpu():
+    """CPU-bandwidth throttling of this container so far (cgroup v2 cpu.stat): periods, throttled periods, throttled microseconds."""
+    out = {}
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec"):
+                out[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 _ALLOC_KEYS = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms", "num_sync_all_streams")
 
 
@@ -210,24 +231,29 @@ def timed_loop(step, first_index, steps, dev):
     time, the caching allocator's device-call counters over the loop (a hipMalloc / hipFree inside it is a device synchronisation)
     and the clocks / power the driver reports before and after."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    state0, a0 = gpu_state(dev), alloc_counters(dev)
+    state0, a0, cg0 = gpu_state(dev), alloc_counters(dev), cgroup_cpu()
     torch.cuda.synchronize()
+    host_t = [0.0] * (steps + 1)      # host clock at each step boundary: a step whose ENQUEUE took long names the host as the stalled side
     with GcWatch() as gcw:
         t0 = time.perf_counter()
         for i in range(steps):
             ev[i].record()
+            host_t[i] = time.perf_counter()
             step(first_index + i)
         ev[steps].record()
-        host = time.perf_counter() - t0
+        host_t[steps] = time.perf_counter()
+        host = host_t[steps] - t0
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-    state1, a1 = gpu_state(dev), alloc_counters(dev)
+    state1, a1, cg1 = gpu_state(dev), alloc_counters(dev), cgroup_cpu()
     per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     diag = {"gpu_elapsed_ms_per_step": ev[0].elapsed_time(ev[steps]) / steps,
             "gpu_step_ms": {"min": per[0], "median": per[len(per) // 2], "max": per[-1],
                             "all": [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(steps)] if steps <= 64 else None},
+            "host_enqueue_ms_by_step": [round((host_t[i + 1] - host_t[i]) * 1e3, 2) for i in range(steps)] if steps <= 64 else None,
             "allocator_delta": {k: a1[k] - a0[k] for k in _ALLOC_KEYS},
             "python_gc_in_timed_loop": gcw.summary(),
+            "cgroup_cpu_delta": {k: cg1[k] - cg0[k] for k in cg1 if k in cg0}, "torch_num_threads": torch.get_num_threads(),
             "allocator_after": {"reserved_gb": a1["reserved_gb"], "allocated_gb": a1["allocated_gb"]},
             "gpu_state_before": state0, "gpu_state_after": state1}
     return wall, host, diag
@@ -276,6 +302,9 @@ def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False, force_d
         out = {"value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                "host_enqueue_ms_per_step": host1, "host_over_gpu": host1 / (dt / steps * 1e3), "host_loop_ms_per_step": host / steps * 1e3,
                "dtype": "bf16" if str(precision) == "bf16" else "f32", "peak_device_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+               # the same count of images over the MEDIAN step time: what the run gives when no single step is stalled by the host (`value` is the mean,
+               # stalls included; `gpu_step_ms` / `host_enqueue_ms_by_step` / `cgroup_cpu_delta` / `python_gc_in_timed_loop` say which steps and why)
+               "images_per_s_at_median_step": batch / (diag["gpu_step_ms"]["median"] * 1e-3),
                "backend": "rccl (world size 1, bucketed GradReducer)" if force_dist else "none",
                "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, z=%dx%dx16, B=%d/GPU, %s%s, %s"
                           % (res, res, lat, lat, batch,
@@ -381,6 +410,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    if os.environ.get("ODVAE_BENCH_HOST_THREADS", "") != "0":      # (0: leave torch's default pool, for A/B)
+        torch.set_num_threads(int(os.environ.get("ODVAE_BENCH_HOST_THREADS", "0")) or max(1, min(4, host_cores() // max(1, world))))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -434,21 +465,24 @@ def main():
         ops.KERNEL_EVENTS.sample = 8 if args.bf16 else 1
     sample = 8 if (args.bf16 and not args.no_kernel_events) else 1   # launches / share below are scaled back by it (estimates when > 1)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # one per step boundary, on the launch stream
-    state0, alloc0 = gpu_state(dev), alloc_counters(dev)
+    state0, alloc0, cg0 = gpu_state(dev), alloc_counters(dev), cgroup_cpu()
     gcw = GcWatch().__enter__()
     t0 = time.perf_counter()
+    host_t = [0.0] * (args.steps + 1)
     for i in range(args.steps):
         step_ev[i].record()
+        host_t[i] = time.perf_counter()
         step(args.warmup + i)
     step_ev[args.steps].record()
-    host_s = time.perf_counter() - t0      # the host has enqueued every launch of the timed steps; the GPU is still working
+    host_t[args.steps] = time.perf_counter()
+    host_s = host_t[args.steps] - t0      # the host has enqueued every launch of the timed steps; the GPU is still working
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gcw.__exit__()
-    state1, alloc1 = gpu_state(dev), alloc_counters(dev)
+    state1, alloc1, cg1 = gpu_state(dev), alloc_counters(dev), cgroup_cpu()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -495,8 +529,10 @@ def main():
             "gpu_step_ms": (lambda per: {"min": min(per), "median": sorted(per)[len(per) // 2], "max": max(per),
                                          "all": [round(v, 3) for v in per] if len(per) <= 64 else None})(
                 [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]),
+            "host_enqueue_ms_by_step": [round((host_t[i + 1] - host_t[i]) * 1e3, 2) for i in range(args.steps)] if args.steps <= 64 else None,
             "allocator_delta": {k: alloc1[k] - alloc0[k] for k in _ALLOC_KEYS},
             "python_gc_in_timed_loop": gcw.summary(),
+            "cgroup_cpu_delta": {k: cg1[k] - cg0[k] for k in cg1 if k in cg0}, "torch_num_threads": torch.get_num_threads(),
             "gpu_state_before": state0, "gpu_state_after": state1,
             "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, B=%d/GPU, %s, VAE phase"
                        % (args.res, args.res, args.batch,
@@ -595,10 +631,10 @@ def main():
             # order: the bf16 run at the headline shape goes FIRST (fresh allocator, nothing bf16 has run yet) and is repeated LAST,
             # after the 512x512 run and the GAN run, so the record itself shows whether its rate depends on what ran before it
             oc = {}
-            oc["configs[1] shape (256x256, B=32) in bf16 mixed precision"] = side_run(dev, 256, 32, 15, 5, False, "bf16")
+            oc["configs[1] shape (256x256, B=32) in bf16 mixed precision"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
             oc["configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder"] = side_run(dev, 512, 32, 4, 2, True, "bf16")
             oc["configs[3] 256x256 B=32 fp32, PatchGAN discriminator + LPIPS-style loss, both optimizers"] = side_run(dev, 256, 32, 4, 2, False, 32, gan=True)
-            oc["configs[1] shape in bf16, repeated after the 512x512 and GAN runs"] = side_run(dev, 256, 32, 15, 5, False, "bf16")
+            oc["configs[1] shape in bf16, repeated after the 512x512 and GAN runs"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
             oc["configs[1] (256x256, B=32, fp32) through the data-parallel path: RCCL world size 1, bucketed reducer"] = \
                 side_run(dev, 256, 32, 6, 2, False, 32, force_dist=True)
             out["other_configs"] = oc

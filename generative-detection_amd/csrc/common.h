@@ -35,6 +35,10 @@ extern "C" void odvae_set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+// One weight of a batched pack launch (odvae_*_pack_*_batch): OIHW f32 weight, its forward / data-gradient pack buffers (either may be null),
+// channel counts, taps (9 or 1; bf16 packs only).  The channel counts of a batched item need no padding in either pack.
+struct OdvaePackItem { const float* w; void* fwd; void* dgr; int Cout, Cin, taps, reserved; };
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

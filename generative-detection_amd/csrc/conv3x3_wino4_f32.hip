@@ -412,9 +412,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
 
 // U[xi = 6a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles.  One thread per
 // (co, ci) pair; padding entries of the packs are zero-filled by the launcher beforehand.
+// items != null: batched launch, blockIdx.y selects the weight (unpadded channel counts: the pads are the counts themselves)
 __global__ void conv3x3_pack_wino4_kernel(const float* __restrict__ w, int Cout, int Cin,
                                           float* __restrict__ fwd, int CinP_f, int CoutP_f,
-                                          float* __restrict__ dgr, int CoutP_d, int CinP_d) {
+                                          float* __restrict__ dgr, int CoutP_d, int CinP_d, const OdvaePackItem* __restrict__ items) {
+  if (items) {
+    const OdvaePackItem it = items[blockIdx.y];
+    w = it.w; Cout = it.Cout; Cin = it.Cin; fwd = static_cast<float*>(it.fwd); dgr = static_cast<float*>(it.dgr);
+    CinP_f = Cin; CoutP_f = Cout; CoutP_d = Cout; CinP_d = Cin;
+  }
   const int64_t pairs = (int64_t)Cout * Cin;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (int64_t)gridDim.x * blockDim.x) {
     const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
@@ -493,8 +499,18 @@ int odvae_conv3x3_pack_wino4_f32(const float* w, int Cout, int Cin, float* fwd_p
   }
   const int blocks = (int)std::min<int64_t>(ceil_div64((int64_t)Cout * Cin, 256), 2048);
   hipLaunchKernelGGL(conv3x3_pack_wino4_kernel, dim3(blocks), dim3(256), 0, st,
-                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d);
+                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d, (const OdvaePackItem*)nullptr);
   ODVAE_LAUNCH_CHECK("conv3x3_pack_wino4");
+  return ODVAE_OK;
+}
+
+// n weights in ONE launch: items = device array of n OdvaePackItem, channel counts their own pads (multiples of 64).  40-44 launches of
+// ~15 us per f32 training step become one.
+int odvae_conv3x3_pack_wino4_batch(const void* items, int n, void* stream) {
+  ODVAE_CHECK_ARG(items && n > 0 && n <= 65535, "conv3x3_pack_wino4_batch: bad arguments");
+  hipLaunchKernelGGL(conv3x3_pack_wino4_kernel, dim3(256, n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)nullptr, 0, 0, (float*)nullptr, 0, 0, (float*)nullptr, 0, 0, static_cast<const OdvaePackItem*>(items));
+  ODVAE_LAUNCH_CHECK("conv3x3_pack_wino4_batch");
   return ODVAE_OK;
 }
 

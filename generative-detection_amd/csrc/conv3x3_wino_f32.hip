@@ -484,9 +484,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino8_kernel(WinoParams p) {
 // U[xi = 4a + b][ci][co] = (G g G^T)[a][b];  dgrad: g taken with flipped taps and swapped channel roles.
 // One thread per (co, ci) pair: reads the nine weights once and writes its 16 (+16) pack entries; padding entries of the
 // packs are zero-filled by the launcher (hipMemsetAsync) beforehand.
+// items != null: batched launch, blockIdx.y selects the weight (unpadded channel counts: the pads are the counts themselves)
 __global__ void conv3x3_pack_wino_kernel(const float* __restrict__ w, int Cout, int Cin,
                                          float* __restrict__ fwd, int CinP_f, int CoutP_f,
-                                         float* __restrict__ dgr, int CoutP_d, int CinP_d) {
+                                         float* __restrict__ dgr, int CoutP_d, int CinP_d, const OdvaePackItem* __restrict__ items) {
+  if (items) {
+    const OdvaePackItem it = items[blockIdx.y];
+    w = it.w; Cout = it.Cout; Cin = it.Cin; fwd = static_cast<float*>(it.fwd); dgr = static_cast<float*>(it.dgr);
+    CinP_f = Cin; CoutP_f = Cout; CoutP_d = Cout; CinP_d = Cin;
+  }
   const int64_t pairs = (int64_t)Cout * Cin;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < pairs; idx += (int64_t)gridDim.x * blockDim.x) {
     // co fastest: the forward pack is co-contiguous, so a wavefront writes 64 consecutive float4 slots' lanes
@@ -550,8 +556,19 @@ int odvae_conv3x3_pack_wino_f32(const float* w, int Cout, int Cin, float* fwd_pa
   }
   const int blocks = (int)std::min<int64_t>(ceil_div64((int64_t)Cout * Cin, 256), 2048);
   hipLaunchKernelGGL(conv3x3_pack_wino_kernel, dim3(blocks), dim3(256), 0, st,
-                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d);
+                     w, Cout, Cin, fwd_pack, CinP_f, CoutP_f, dgrad_pack, CoutP_d, CinP_d, (const OdvaePackItem*)nullptr);
   ODVAE_LAUNCH_CHECK("conv3x3_pack_wino");
+  return ODVAE_OK;
+}
+
+// The same for n weights in ONE launch: items = device array of n OdvaePackItem (common.h: w, fwd pack, dgrad pack, Cout, Cin), every
+// channel count its own pad (odvae_conv3x3_wino_reduce_pad(c) == odvae_conv3x3_wino_out_pad(c) == c).  A training step repacks ~20
+// weights of this kind after every optimizer step: 20 launches of 30 us each become one.
+int odvae_conv3x3_pack_wino_batch(const void* items, int n, void* stream) {
+  ODVAE_CHECK_ARG(items && n > 0 && n <= 65535, "conv3x3_pack_wino_batch: bad arguments");
+  hipLaunchKernelGGL(conv3x3_pack_wino_kernel, dim3(256, n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const float*)nullptr, 0, 0, (float*)nullptr, 0, 0, (float*)nullptr, 0, 0, static_cast<const OdvaePackItem*>(items));
+  ODVAE_LAUNCH_CHECK("conv3x3_pack_wino_batch");
   return ODVAE_OK;
 }
 

@@ -128,6 +128,7 @@ class _PackCache:
     def __init__(self):
         self.epoch = 0
         self.store = {}
+        self._tables = {}
 
     def bump(self):
         self.epoch += 1
@@ -141,6 +142,10 @@ class _PackCache:
             return hit[2], hit[3]
         reuse = None
         if same and self.INPLACE and hit[4] == (tuple(weight.shape), weight.device) and (hit[3] is not None or not want_dgrad):
+            if self.BATCH and up in _BATCH_KINDS and self._refresh_kind(up, weight.device):
+                hit = self.store.get(key)
+                if hit is not None and hit[1] == tag:
+                    return hit[2], hit[3]
             reuse = (hit[2], hit[3])          # refill the buffers this weight's packs already live in
             want_dgrad = hit[3] is not None
         fwd, dgr = _pack_conv3x3_now(weight, True, want_dgrad, up, into=reuse)
@@ -153,10 +158,62 @@ class _PackCache:
         store[key] = (ref, tag, fwd, dgr, (tuple(weight.shape), weight.device))
         return fwd, dgr
 
+    # One launch per pack KIND instead of one per weight: the first stale hit after a weight update refills every stale entry of that
+    # kind (the training step repacks 88 bf16 / 64 Winograd weight packs after every optimizer step: 7-30 us launches, mostly overhead).
+    # The device table of (weight, pack, pack, Cout, Cin, taps) records is rebuilt only when the set of entries changes: parameters live
+    # in the optimizer's arena and the packs are refilled in place, so the pointers are the same step after step.
+    BATCH = os.environ.get("ODVAE_PACK_BATCH", "1") != "0"
+
+    def _refresh_kind(self, kind, device):
+        import numpy as np
+        L = _L()
+        live = []
+        for key, ent in self.store.items():
+            if key[1] != kind or ent[2] is None:
+                continue
+            w = ent[0]()
+            if w is None or w.device != device or ent[4] != (tuple(w.shape), w.device) or not w.is_contiguous() or w.dtype != torch.float32:
+                continue
+            tag = (w.data_ptr(), w._version, self.epoch)
+            if ent[1] == tag or not _batchable(kind, w, L):
+                continue
+            live.append((key, ent, w, tag))
+        if len(live) < 2:
+            return False
+        sig = tuple((k, e[2].data_ptr(), 0 if e[3] is None else e[3].data_ptr(), w.data_ptr()) for k, e, w, _ in live)
+        cached = self._tables.get((kind, device))
+        if cached is None or cached[0] != sig:
+            rec = np.zeros(len(live), dtype=np.dtype([("w", "<u8"), ("fwd", "<u8"), ("dgr", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"), ("pad", "<i4")]))
+            for i, (_, e, w, _) in enumerate(live):
+                rec[i] = (w.data_ptr(), e[2].data_ptr(), 0 if e[3] is None else e[3].data_ptr(), w.shape[0], w.shape[1], w.shape[2] * w.shape[3], 0)
+            table = _lib.upload(torch.from_numpy(rec.view(np.uint8).copy()), device)
+            cached = self._tables[(kind, device)] = (sig, table)
+        fn = {"wino": L.odvae_conv3x3_pack_wino_batch, "wino4": L.odvae_conv3x3_pack_wino4_batch, "bf16": L.odvae_conv_pack_bf16_batch}[kind]
+        _lib.check(fn(cached[1].data_ptr(), len(live), _lib.stream_ptr()), "pack batch (%s)" % kind)
+        for key, e, w, tag in live:
+            self.store[key] = (e[0], tag, e[2], e[3], e[4])
+        return True
+
     def check_epoch(self, epoch, what):
         if epoch != self.epoch:
             raise RuntimeError("%s: the weights were updated (optimizer step) between this graph's forward and its backward; the "
                                "cached weight packs now hold the new weights" % what)
+
+
+_BATCH_KINDS = ("wino", "wino4", "bf16")
+
+
+def _batchable(kind, w, L):
+    """Shapes the batched pack kernels take: the Winograd packs without padding in either direction (the single-weight launcher zero-fills
+    padding with a memset first); bf16 packs always (the kernel writes every element, padding included)."""
+    cout, cin = w.shape[0], w.shape[1]
+    if kind == "bf16":
+        return True
+    if tuple(w.shape[2:]) != (3, 3):
+        return False
+    rp, op = ((L.odvae_conv3x3_wino_reduce_pad, L.odvae_conv3x3_wino_out_pad) if kind == "wino"
+              else (L.odvae_conv3x3_wino4_reduce_pad, L.odvae_conv3x3_wino4_out_pad))
+    return rp(cin) == cin and op(cout) == cout and rp(cout) == cout and op(cin) == cin
 
 
 PACK_CACHE = _PackCache()

@@ -663,3 +663,28 @@ def test_thin_output_conv(hip_lib, n, cout, h, w):
     close(bd.grad, br.grad, BWD_TOL * 4, "db")
     # without a bias
     close(ops.conv3x3(xd.detach(), wd.detach(), None), F.conv2d(x, wt, None, padding=1), FWD_TOL, "thin-output conv, no bias")
+
+
+@pytest.mark.parametrize("kind,shapes", [("wino4", [(64, 64), (128, 64), (64, 128), (256, 256)]), ("wino", [(64, 64), (128, 128), (128, 64)]),
+                                        ("bf16", [(128, 64, 3), (192, 128, 1), (40, 24, 3), (512, 256, 3)])])
+def test_batched_weight_packs_equal_the_single_launches(hip_lib, monkeypatch, kind, shapes):
+    """After a weight update the pack cache refills every stale pack of a kind with ONE launch (`odvae_*_pack_*_batch`, a device table of
+    weight / pack pointers): the packs it leaves are bit-identical to what the per-weight launches write, forward and data-gradient
+    side, in place (same buffers as before the update), including weights whose data-gradient pack was never asked for."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "PACK_CACHE", ops._PackCache())
+    g = torch.Generator().manual_seed(len(shapes))
+    ws = [torch.randn(s[0], s[1], *( (s[2], s[2]) if len(s) > 2 else (3, 3)), generator=g).to(dev()) for s in shapes]
+    first = [ops.pack_conv3x3(w, True, i != 1, kind) for i, w in enumerate(ws)]      # weight 1: forward pack only
+    ptrs = [(f.data_ptr(), None if d is None else d.data_ptr()) for f, d in first]
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5).add_(0.25)
+    ops.PACK_CACHE.bump()
+    got = [ops.pack_conv3x3(w, True, i != 1, kind) for i, w in enumerate(ws)]
+    assert len(ops.PACK_CACHE._tables) == 1                      # the batched path ran
+    for i, w in enumerate(ws):
+        f, d = ops._pack_conv3x3_now(w, True, i != 1, kind)
+        assert (got[i][0].data_ptr(), None if got[i][1] is None else got[i][1].data_ptr()) == ptrs[i]
+        assert torch.equal(got[i][0], f)
+        assert (d is None and got[i][1] is None) or torch.equal(got[i][1], d)
