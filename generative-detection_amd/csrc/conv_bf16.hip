@@ -300,17 +300,10 @@ __global__ __launch_bounds__(256, MINW) void conv_bf16_kernel(ConvB p) {
 //   dgrad: reduce over Cout, rows = Cin:   W'[tap][ci][co] = w[co][ci][flip(tap)]   (MODE 0 / 4 data gradient; MODE 3 uses
 //          the same flipped pack: dx = transposed conv of dy)
 // layout [tap][RP/16][OP/32][lane 64][8]: lane (r, h) element j = W[row 32*ot + r][k = 16*kt + 8h + j]
-// items != null: batched launch, blockIdx.y selects the weight; its pads are recomputed here from the channel counts
+// (a batched form -- all 88 packs of a bf16 step in one launch right after the optimizer step, as the f32 Winograd packs are made -- was
+// measured 0.3-0.65 ms per step SLOWER: a pack written just before its conv is read from L2, one written a whole forward earlier from HBM)
 __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
-                                      bf16_t* __restrict__ fwd, int RP_f, int OP_f, bf16_t* __restrict__ dgr, int RP_d, int OP_d,
-                                      const OdvaePackItem* __restrict__ items) {
-  if (items) {
-    const OdvaePackItem it = items[blockIdx.y];
-    w = it.w; Cout = it.Cout; Cin = it.Cin; taps = it.taps; fwd = static_cast<bf16_t*>(it.fwd); dgr = static_cast<bf16_t*>(it.dgr);
-    auto rpad = [](int c) { return c % 64 == 0 ? c : (c + 31) / 32 * 32; };
-    auto opad = [](int c) { return c > 64 ? (c + 127) / 128 * 128 : (c > 32 ? 64 : 32); };
-    RP_f = rpad(Cin); OP_f = opad(Cout); RP_d = rpad(Cout); OP_d = opad(Cin);
-  }
+                                      bf16_t* __restrict__ fwd, int RP_f, int OP_f, bf16_t* __restrict__ dgr, int RP_d, int OP_d) {
   const int64_t nf = fwd ? (int64_t)taps * RP_f * OP_f : 0;
   const int64_t nd = dgr ? (int64_t)taps * RP_d * OP_d : 0;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -375,20 +368,11 @@ int odvae_conv_pack_bf16(const float* w, int Cout, int Cin, int taps, void* fwd_
   const int blocks = (int)std::min<int64_t>(ceil_div64(total, 256), 4096);
   hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, Cout, Cin, taps,
                      static_cast<bf16_t*>(fwd_pack), odvae_conv_bf16_reduce_pad(Cin), odvae_conv_bf16_out_pad(Cout),
-                     static_cast<bf16_t*>(dgrad_pack), odvae_conv_bf16_reduce_pad(Cout), odvae_conv_bf16_out_pad(Cin), (const OdvaePackItem*)nullptr);
+                     static_cast<bf16_t*>(dgrad_pack), odvae_conv_bf16_reduce_pad(Cout), odvae_conv_bf16_out_pad(Cin));
   ODVAE_LAUNCH_CHECK("conv_pack_bf16");
   return ODVAE_OK;
 }
 
-// n weights in ONE launch: items = device array of n OdvaePackItem (taps 9 or 1 per item; the kernel writes every element of a pack,
-// padding included, so any channel counts the single call takes are fine).  The bf16 step repacks 88 weights after every optimizer step.
-int odvae_conv_pack_bf16_batch(const void* items, int n, void* stream) {
-  ODVAE_CHECK_ARG(items && n > 0 && n <= 65535, "conv_pack_bf16_batch: bad arguments");
-  hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(128, n), dim3(256), 0, static_cast<hipStream_t>(stream), (const float*)nullptr, 0, 0, 0,
-                     (bf16_t*)nullptr, 0, 0, (bf16_t*)nullptr, 0, 0, static_cast<const OdvaePackItem*>(items));
-  ODVAE_LAUNCH_CHECK("conv_pack_bf16_batch");
-  return ODVAE_OK;
-}
 
 // y = conv(x) (+ bias) (+ residual).  x bf16 NHWC [N][Hi][Wi][Cin] (Cin % 8 == 0), pack from odvae_conv_pack_bf16 with
 // (reduce = Cin, out = Cout), bias f32 [Cout] or NULL, residual bf16 [N][Ho][Wo][Cout] or NULL, y bf16 (out_f32 = 0; needs

@@ -43,7 +43,6 @@ PROTOTYPES = {
     "odvae_conv3x3_pack_wino4_f32": (_I, [_P, _I, _I, _P, _P, _P]),
     "odvae_conv3x3_pack_wino_batch": (_I, [_P, _I, _P]),
     "odvae_conv3x3_pack_wino4_batch": (_I, [_P, _I, _P]),
-    "odvae_conv_pack_bf16_batch": (_I, [_P, _I, _P]),
     "odvae_conv3x3_wino4_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "odvae_conv3x3_wino4_stats_chunks": (_I, [_I, _I]),
     "odvae_conv3x3_wino4_stats_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),

@@ -159,7 +159,7 @@ class _PackCache:
         return fwd, dgr
 
     # One launch per pack KIND instead of one per weight: the first stale hit after a weight update refills every stale entry of that
-    # kind (the training step repacks 88 bf16 / 64 Winograd weight packs after every optimizer step: 7-30 us launches, mostly overhead).
+    # kind (the f32 training step repacks 64 Winograd weight packs after every optimizer step: 15-30 us launches, mostly overhead; 234.7 -> 234.4 ms).
     # The device table of (weight, pack, pack, Cout, Cin, taps) records is rebuilt only when the set of entries changes: parameters live
     # in the optimizer's arena and the packs are refilled in place, so the pointers are the same step after step.
     BATCH = os.environ.get("ODVAE_PACK_BATCH", "1") != "0"
@@ -188,7 +188,7 @@ class _PackCache:
                 rec[i] = (w.data_ptr(), e[2].data_ptr(), 0 if e[3] is None else e[3].data_ptr(), w.shape[0], w.shape[1], w.shape[2] * w.shape[3], 0)
             table = _lib.upload(torch.from_numpy(rec.view(np.uint8).copy()), device)
             cached = self._tables[(kind, device)] = (sig, table)
-        fn = {"wino": L.odvae_conv3x3_pack_wino_batch, "wino4": L.odvae_conv3x3_pack_wino4_batch, "bf16": L.odvae_conv_pack_bf16_batch}[kind]
+        fn = {"wino": L.odvae_conv3x3_pack_wino_batch, "wino4": L.odvae_conv3x3_pack_wino4_batch}[kind]
         _lib.check(fn(cached[1].data_ptr(), len(live), _lib.stream_ptr()), "pack batch (%s)" % kind)
         for key, e, w, tag in live:
             self.store[key] = (e[0], tag, e[2], e[3], e[4])
@@ -200,15 +200,13 @@ class _PackCache:
                                "cached weight packs now hold the new weights" % what)
 
 
-_BATCH_KINDS = ("wino", "wino4", "bf16")
+_BATCH_KINDS = ("wino", "wino4")      # (bf16 packs: batching measured 0.3-0.65 ms per step slower, see conv_bf16.hip)
 
 
 def _batchable(kind, w, L):
     """Shapes the batched pack kernels take: the Winograd packs without padding in either direction (the single-weight launcher zero-fills
-    padding with a memset first); bf16 packs always (the kernel writes every element, padding included)."""
+    padding with a memset first)."""
     cout, cin = w.shape[0], w.shape[1]
-    if kind == "bf16":
-        return True
     if tuple(w.shape[2:]) != (3, 3):
         return False
     rp, op = ((L.odvae_conv3x3_wino_reduce_pad, L.odvae_conv3x3_wino_out_pad) if kind == "wino"

@@ -101,10 +101,11 @@ int odvae_conv3x3_wino4_supported(int H, int W, int Cin, int Cout);
 int odvae_conv3x3_pack_wino4_f32(const float* w_oihw, int Cout, int Cin, float* fwd_pack, float* dgrad_pack, void* stream);
 /* Batched packs: ONE launch for n weights (a training step repacks every conv weight after each optimizer step).  items = device array of
  * n records {const float* w; void* fwd_pack; void* dgrad_pack; int Cout, Cin, taps, reserved;} (40 bytes, natural alignment; either pack
- * may be NULL).  F(2x2) / F(4x4): channel counts that need no padding (c == *_reduce_pad(c) == *_out_pad(c)); bf16: any counts, taps 9 or 1. */
+ * may be NULL), channel counts that need no padding (c == *_reduce_pad(c) == *_out_pad(c)).  (The bf16 packs stay per weight: batching them
+ * was measured slower -- a pack made right before its conv is still in L2 when the conv reads it.) */
 int odvae_conv3x3_pack_wino_batch(const void* items, int n, void* stream);
 int odvae_conv3x3_pack_wino4_batch(const void* items, int n, void* stream);
-int odvae_conv_pack_bf16_batch(const void* items, int n, void* stream);
+
 int odvae_conv3x3_wino4_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
                             const float* bias, const float* residual, float* y, int act /* must be 0: no fused activation */, void* stream);
 /* The same, and the output transform also leaves the GroupNorm statistics of y for the layer that reads it (GroupNorm row:

@@ -665,8 +665,7 @@ def test_thin_output_conv(hip_lib, n, cout, h, w):
     close(ops.conv3x3(xd.detach(), wd.detach(), None), F.conv2d(x, wt, None, padding=1), FWD_TOL, "thin-output conv, no bias")
 
 
-@pytest.mark.parametrize("kind,shapes", [("wino4", [(64, 64), (128, 64), (64, 128), (256, 256)]), ("wino", [(64, 64), (128, 128), (128, 64)]),
-                                        ("bf16", [(128, 64, 3), (192, 128, 1), (40, 24, 3), (512, 256, 3)])])
+@pytest.mark.parametrize("kind,shapes", [("wino4", [(64, 64), (128, 64), (64, 128), (256, 256)]), ("wino", [(64, 64), (128, 128), (128, 64)])])
 def test_batched_weight_packs_equal_the_single_launches(hip_lib, monkeypatch, kind, shapes):
     """After a weight update the pack cache refills every stale pack of a kind with ONE launch (`odvae_*_pack_*_batch`, a device table of
     weight / pack pointers): the packs it leaves are bit-identical to what the per-weight launches write, forward and data-gradient
