@@ -55,7 +55,19 @@ struct Wino4Params {
                           // upsampled image is fetched from x[iy >> 1][ix >> 1]; H, W are the OUTPUT's
   float* gn_partial;      // [N][tiles per image][gn_groups][2] (sum, sum of squares of y per tile and channel group) or null
   int gn_groups, gn_cpg;  // channel groups of the GroupNorm that reads y, channels per group (a power of two <= 32)
+  // EPI_GNBWD (this launch is the data gradient of a conv whose INPUT was a = swish(GroupNorm(gx)); y = da): the output transform also
+  // leaves the first pass of that GroupNorm's backward -- per tile and channel the sums of du * xhat and du, du = da * swish'(u),
+  // u = xhat * gamma + beta -- in gn_partial [N][tiles per image][2][Cout], the layout gn_bwd_reduce_kernel writes (groupnorm.hip)
+  const float* gn_x;      // [N][H][W][Cout]: the GroupNorm's input
+  const float* gn_mean;   // [N][gn_groups]
+  const float* gn_rstd;   // [N][gn_groups]
+  const float* gn_gamma;  // [Cout]
+  const float* gn_beta;   // [Cout]
 };
+constexpr int EPI_NONE = 0, EPI_STATS = 1, EPI_GNBWD = 2, EPI_POOL = 3;
+// EPI_POOL (the data gradient of an Upsample conv: y = the gradient w.r.t. the LOW-resolution input [N][H/2][W/2][Cout]): every thread
+// of the output transform holds a 4x4 pixel block of one channel, so the 2x2 sums that nearest-2x upsampling's backward takes are formed
+// in registers -- 4 stores instead of 16, and the full-resolution gradient never reaches HBM (upsample2x_bwd_kernel: 0.4 ms per step)
 
 __device__ __forceinline__ f32x2 lds_ld64f(unsigned a) { return *(const __attribute__((address_space(3))) f32x2*)(uintptr_t)a; }
 __device__ __forceinline__ void lds_st64f(unsigned a, f32x2 v) { *(__attribute__((address_space(3))) f32x2*)(uintptr_t)a = v; }
@@ -85,8 +97,11 @@ __device__ __forceinline__ void column_pass_store(const f32x2 (&t)[6], unsigned 
 // two accumulators and the exchange live only in the instantiation the statistics launches use, so the data-gradient launches and every
 // launch without a GroupNorm consumer run the plain build (255 registers, no scratch).
 // UP: the Upsample form (x at half resolution, Wino4Params::up), likewise compiled in only where it is launched.
-template <bool STATS, bool UP>
+// EPI_GNBWD: the reduce pass of the GroupNorm backward that follows a data-gradient launch, from the same output transform (Wino4Params):
+// that pass otherwise streams gx and da from HBM once more (5.7 of the f32 step's 232 ms); here da is in registers and only gx is read.
+template <int EPI, bool UP>
 __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
+  constexpr bool STATS = EPI == EPI_STATS, GNB = EPI == EPI_GNBWD, POOL = EPI == EPI_POOL;
   extern __shared__ __attribute__((aligned(16))) float dsmem[];
   const unsigned lds0 = lds_addr_of(dsmem);
   const unsigned halo0 = lds0, v0 = lds0 + 2 * HALO_B;
@@ -295,14 +310,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   asm volatile("" : "+v"(lane_e));
   const int li_e = lane_e & 31, h_e = lane_e >> 5;
   const unsigned X0 = v0;
-  const int img_bytes = p.H * p.W * p.Cout * 4;
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.H * p.W * p.Cout, 0, img_bytes, 0x00020000);
+  const int img_bytes = POOL ? (p.H >> 1) * (p.W >> 1) * p.Cout * 4 : p.H * p.W * p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * (img_bytes >> 2), 0, img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.residual ? p.residual : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, p.residual ? img_bytes : 0, 0x00020000);
   const int ct2 = wave & 1, e2 = wave >> 1;        // the (co tile, register) this thread finishes in every pass
   const int co = n0 + ct2 * 32 + li_e;
-  const float bv = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
-  const int cstep = p.Cout * 4, rstep = p.W * p.Cout * 4;
+  const float bv = (!GNB && p.bias && co < p.Cout) ? p.bias[co] : 0.f;      // (a data gradient has neither bias nor residual)
+  const __amdgpu_buffer_rsrc_t gxrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(GNB ? p.gn_x : p.y) + (int64_t)n * p.H * p.W * p.Cout, 0, GNB ? img_bytes : 0, 0x00020000);
+  float g_mu = 0.f, g_rs = 0.f, g_ga = 0.f, g_be = 0.f;      // GNB: this thread's channel of the GroupNorm (one channel, one image per tile)
+  if (GNB && co < p.Cout) {
+    g_mu = p.gn_mean[n * p.gn_groups + co / p.gn_cpg]; g_rs = p.gn_rstd[n * p.gn_groups + co / p.gn_cpg];
+    g_ga = p.gn_gamma[co]; g_be = p.gn_beta[co];
+  }
+  const int cstep = p.Cout * 4, rstep = (POOL ? p.W >> 1 : p.W) * p.Cout * 4;
   const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane_e) * 4);
   const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane_e) * 4);
 #pragma unroll
@@ -313,23 +335,33 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       for (int e = 0; e < 4; ++e) if (!(ODVAE_W4_ABL & 256)) lds_st32f(x_wr + (j * 4 + e) * 256, acc[j][4 * rq + e]);
     // element (register 4 rq + e2, lane) is tile (row rq, column 4 h + e2): a 4x4 pixel block of one output channel
     const int py = oy0 + 4 * rq, px = ox0 + 4 * (4 * h_e + e2);
-    const unsigned base = (py < p.H && px < p.W && co < p.Cout) ? (unsigned)(((py * p.W + px) * p.Cout + co) * 4) : OOB;
+    const unsigned base = !(py < p.H && px < p.W && co < p.Cout) ? OOB
+                        : POOL ? (unsigned)((((py >> 1) * (p.W >> 1) + (px >> 1)) * p.Cout + co) * 4) : (unsigned)(((py * p.W + px) * p.Cout + co) * 4);
     float seed[4][4];      // bias (+ residual, requested before the exchange barrier)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) seed[a][c] = bv;
-    if (p.residual) {
+    if (!GNB && p.residual) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           seed[a][c] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, base, a * rstep + c * cstep, 0));
     }
+    float gx[4][4];       // GNB: the GroupNorm input at this thread's 16 pixels (requested before the exchange barrier, like a residual)
+    if (GNB) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          gx[a][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gxrsrc, base, a * rstep + c * cstep, 0));
+    }
     if (!(ODVAE_W4_ABL & 512)) __syncthreads();
     float psum = 0.f, psq = 0.f;      // STATS: this pass's share of the GroupNorm statistics; parked in LDS at the end of the pass, so
                                       // that nothing of it stays in a register across the passes (with two accumulators live over
                                       // the whole output transform hipcc spilled nine registers into scratch)
+    float pool[2] = {0.f, 0.f};
     float tt[6][4];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -350,27 +382,46 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
       yv[1] = d1 + 2.f * d2 + seed[1][c];
       yv[2] = s1 + 4.f * s2 + seed[2][c];
       yv[3] = d1 + 8.f * d2 + tt[5][c] + seed[3][c];
+      if (POOL) {      // rows (0,1) and (2,3) of this column join the column pair's sums; stored after the second column of a pair
+        if ((c & 1) == 0) { pool[0] = yv[0] + yv[1]; pool[1] = yv[2] + yv[3]; }
+        else {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pool[0] + (yv[0] + yv[1])), yrsrc, base, (c >> 1) * cstep, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pool[1] + (yv[2] + yv[3])), yrsrc, base, rstep + (c >> 1) * cstep, 0);
+        }
+      } else {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (!(ODVAE_W4_ABL & 128) || yv[a] == 12345.678f)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
+        for (int a = 0; a < 4; ++a)
+          if (!(ODVAE_W4_ABL & 128) || yv[a] == 12345.678f)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[a]), yrsrc, base, a * rstep + c * cstep, 0);
+      }
       if (STATS && base != OOB) {      // (a 4x4 tile is inside the image as a whole: H and W are multiples of 4)
 #pragma unroll
         for (int a = 0; a < 4; ++a) { psum += yv[a]; psq += yv[a] * yv[a]; }
       }
+      if (GNB && base != OOB) {        // psum: du * xhat, psq: du  (gn_bwd_reduce_kernel's a, b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float xh = (gx[a][c] - g_mu) * g_rs;
+          const float u = xh * g_ga + g_be;
+          const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-u));
+          const float du = yv[a] * (sg * (1.f + u * (1.f - sg)));
+          psum += du * xh; psq += du;
+        }
+      }
     }
-    if (STATS) {
+    if (STATS || GNB) {
       lds_st32f(lds0 + LDS_B + (unsigned)((rq * 512 + tid) * 8), psum);
       lds_st32f(lds0 + LDS_B + (unsigned)((rq * 512 + tid) * 8 + 4), psq);
     }
     // the next tile's halo: with a residual the 16 loads + 16 stores of pass 0 are younger than it, without one the 32 stores of passes 0, 1
-    if (has_next && rq == (p.residual ? 0 : 1)) wait_vm_but<32>();
+    // (EPI_POOL writes 4 values per pass: its two halo chunks are awaited outright after pass 1 -- 8 stores younger)
+    if (has_next && rq == ((!GNB && p.residual) || GNB ? 0 : 1)) { if (POOL) wait_vm_but<8>(); else wait_vm_but<32>(); }
     if (rq < 3 && !(ODVAE_W4_ABL & 512)) __syncthreads();     // X is rewritten by the next pass
   }
   // ---- GroupNorm statistics of this tile for the layer that reads y: (sum, sum of squares) per channel group, one slot per
   // (image, tile, group) written by exactly one block -- the consumer's finalize kernel adds the tiles up in f64, in fixed order ----
-  if (STATS) {
-    const int cpg = p.gn_cpg;
+  if (STATS || GNB) {
+    const int cpg = GNB ? 1 : p.gn_cpg;      // GNB: sums per channel, not per group
     float gsum = 0.f, gsq = 0.f;      // this thread's four passes, in pass order (each thread reads back what it wrote itself)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
@@ -397,8 +448,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
           b += lds_ld32f(X0 + (unsigned)(((e * 2 + ctq) * 32 + l) * 8 + 4));
         }
         const int tile_in_image = (oy0 / TH) * p.tiles_x + ox0 / TW;
-        float* dst = p.gn_partial + (((int64_t)n * (p.tiles_x * p.tiles_y) + tile_in_image) * p.gn_groups + cg / cpg) * 2;
-        dst[0] = a; dst[1] = b;
+        if (GNB) {
+          float* dst = p.gn_partial + ((int64_t)n * (p.tiles_x * p.tiles_y) + tile_in_image) * 2 * p.Cout;
+          dst[cg] = a; dst[p.Cout + cg] = b;
+        } else {
+          float* dst = p.gn_partial + (((int64_t)n * (p.tiles_x * p.tiles_y) + tile_in_image) * p.gn_groups + cg / cpg) * 2;
+          dst[0] = a; dst[1] = b;
+        }
       }
     }
   }
@@ -517,8 +573,10 @@ int odvae_conv3x3_pack_wino4_batch(const void* items, int n, void* stream) {
 // tiles per image of the F(4x4) kernel = the chunk count of its GroupNorm partials
 int odvae_conv3x3_wino4_stats_chunks(int H, int W) { return ceil_div(H, TH) * ceil_div(W, TW); }
 
+struct Wino4GnBwd { const float *x, *mean, *rstd, *gamma, *beta; };
 static int wino4_launch(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
-                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream, int up = 0);
+                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream, int up = 0,
+                        const Wino4GnBwd* gnb = nullptr, int pool = 0);
 
 // y = conv3x3_stride1_pad1(x) (+bias) (+residual); upk = fwd or dgrad pack of odvae_conv3x3_pack_wino4_f32; act must be 0
 // (a fused ReLU is not offered: ops.py keeps the ReLU convs of the VGG stack on F(2x2) for accuracy, see there).
@@ -554,8 +612,27 @@ int odvae_conv3x3_wino4_up_f32(const float* x, int N, int H, int W, int Cin, con
   return wino4_launch(x, N, H, W, Cin, upk, Cout, bias, residual, y, 0, gn_partial, gn_partial ? gn_groups : 0, stream, 1);
 }
 
+// Data gradient of a conv whose input was a = swish(GroupNorm(gn_x)) (x = the conv's dy, upk = its dgrad pack, y = da [N][H][W][Cout]), and
+// the first pass of that GroupNorm's backward from the same output transform: gn_partial [N][odvae_conv3x3_wino4_stats_chunks(H, W)][2][Cout]
+// = per tile and channel (sum du * xhat, sum du), every slot written by exactly one block -- the input of odvae_groupnorm_bwd_partials_f32.
+int odvae_conv3x3_wino4_gnbwd_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout, float* y,
+                                  const float* gn_x, const float* gn_mean, const float* gn_rstd, const float* gn_gamma, const float* gn_beta,
+                                  int gn_groups, float* gn_partial, void* stream) {
+  ODVAE_CHECK_ARG(gn_x && gn_mean && gn_rstd && gn_gamma && gn_beta && gn_partial, "conv3x3_wino4_gnbwd: null GroupNorm operand");
+  ODVAE_CHECK_ARG(gn_groups > 0 && Cout % gn_groups == 0, "conv3x3_wino4_gnbwd: %d channels in %d groups", Cout, gn_groups);
+  const Wino4GnBwd g{gn_x, gn_mean, gn_rstd, gn_gamma, gn_beta};
+  return wino4_launch(x, N, H, W, Cin, upk, Cout, nullptr, nullptr, y, 0, gn_partial, gn_groups, stream, 0, &g);
+}
+
+// Data gradient of an Upsample conv w.r.t. its LOW-resolution input: x = the conv's dy [N][H][W][Cin], upk = its data-gradient pack,
+// y [N][H/2][W/2][Cout] = the 2x2 sums of the full-resolution gradient (formed in the output transform; that gradient is never stored).
+int odvae_conv3x3_wino4_pool_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout, float* y, void* stream) {
+  return wino4_launch(x, N, H, W, Cin, upk, Cout, nullptr, nullptr, y, 0, nullptr, 0, stream, 0, nullptr, 1);
+}
+
 static int wino4_launch(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout,
-                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream, int up) {
+                        const float* bias, const float* residual, float* y, int act, float* gn_partial, int gn_groups, void* stream, int up,
+                        const Wino4GnBwd* gnb, int pool) {
   ODVAE_CHECK_ARG(x && upk && y, "conv3x3_wino4: null operand");
   ODVAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wino4: empty shape");
   ODVAE_CHECK_ARG(act == 0, "conv3x3_wino4: no fused activation (act=%d); ReLU convs stay on odvae_conv3x3_wino_f32", act);
@@ -570,13 +647,17 @@ static int wino4_launch(const float* x, int N, int H, int W, int Cin, const floa
   p.tiles_x = ceil_div(W, TW); p.tiles_y = ceil_div(H, TH); p.act = act;
   p.gn_partial = gn_partial; p.gn_groups = gn_groups; p.gn_cpg = gn_groups > 0 ? Cout / gn_groups : 0;
   p.up = up;
+  p.gn_x = gnb ? gnb->x : nullptr; p.gn_mean = gnb ? gnb->mean : nullptr; p.gn_rstd = gnb ? gnb->rstd : nullptr;
+  p.gn_gamma = gnb ? gnb->gamma : nullptr; p.gn_beta = gnb ? gnb->beta : nullptr;
   ODVAE_CHECK_ARG((int64_t)36 * p.CinP * p.CoutP * 4 < 0x7FFFFFF0ll, "conv3x3_wino4: pack too large");
   const int64_t sp = (int64_t)p.tiles_x * p.tiles_y * N;
   ODVAE_CHECK_ARG(sp < (1ll << 31), "conv3x3_wino4: too many tiles");
   static const bool xcd = getenv("ODVAE_TILE_XCD") == nullptr || atoi(getenv("ODVAE_TILE_XCD")) != 0;
   p.xcd = xcd ? 1 : 0;
-  const auto kern = up ? (gn_partial ? conv3x3_wino4_kernel<true, true> : conv3x3_wino4_kernel<false, true>)
-                       : (gn_partial ? conv3x3_wino4_kernel<true, false> : conv3x3_wino4_kernel<false, false>);
+  const auto kern = gnb ? conv3x3_wino4_kernel<EPI_GNBWD, false>
+                  : pool ? conv3x3_wino4_kernel<EPI_POOL, false>
+                  : up ? (gn_partial ? conv3x3_wino4_kernel<EPI_STATS, true> : conv3x3_wino4_kernel<EPI_NONE, true>)
+                       : (gn_partial ? conv3x3_wino4_kernel<EPI_STATS, false> : conv3x3_wino4_kernel<EPI_NONE, false>);
   const unsigned lds_bytes = gn_partial ? LDS_B + STATS_B : LDS_B;
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) {

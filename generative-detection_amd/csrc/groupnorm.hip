@@ -654,4 +654,37 @@ int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int 
   return ODVAE_OK;
 }
 
+// The same with the first pass already done: partial [N][chunks][2][C] = per chunk of pixels and channel (sum du * xhat, sum du), as the
+// data-gradient launch that produced dy left it (odvae_conv3x3_wino4_gnbwd_f32: one chunk per output tile).  x and dy are read once.
+int odvae_groupnorm_bwd_partials_f32(const float* x, const float* dy, int N, int HW, int C, int G,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
+                                     float* dx, float* dgamma, float* dbeta, const float* dx_add, const float* partial, int chunks,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  GnShape s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_bwd_partials: unsupported shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta && partial && chunks > 0, "groupnorm_bwd_partials: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)dx_add & 15) == 0,
+                  "groupnorm_bwd_partials: operands must be 16-byte aligned");
+  const size_t need = ((size_t)N * 2 * C + (size_t)N * G * 2) * sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    odvae_set_error("groupnorm_bwd_partials: needs %zu workspace bytes, got %zu", need, workspace_bytes);
+    return ODVAE_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* chan = static_cast<float*>(workspace);
+  float* grp = chan + (size_t)N * 2 * C;
+  GnShape sp = s;
+  sp.chunks = chunks;
+  if (s.cpg <= 64) hipLaunchKernelGGL(gn_bwd_finalize_kernel<GnShape>, dim3(N, ceil_div(C, (64 / s.cpg) * s.cpg)), dim3(256), 0, st, partial, sp, gamma, chan, grp);
+  else hipLaunchKernelGGL(gn_bwd_finalize_wide_kernel<GnShape>, dim3(N), dim3(256), 2 * C * sizeof(float), st, partial, sp, gamma, chan, grp);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd finalize (partials)");
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, chan, N, C, dgamma, dbeta);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd param (partials)");
+  const dim3 grid(apply_blocks(s), N);
+  if (swish) hipLaunchKernelGGL((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx_add, dx);
+  else       hipLaunchKernelGGL((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, st, x, dy, s, gamma, beta, mean, rstd, grp, dx_add, dx);
+  ODVAE_LAUNCH_CHECK("groupnorm bwd apply (partials)");
+  return ODVAE_OK;
+}
+
 }  // extern "C"

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "odvae_conv3x3_wino4_stats_chunks": (_I, [_I, _I]),
     "odvae_conv3x3_wino4_stats_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "odvae_conv3x3_wino4_up_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P]),
+    "odvae_conv3x3_wino4_pool_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "odvae_conv3x3_wino4_gnbwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "odvae_conv3x3_f32": (_I, [_I, _P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "odvae_conv3x3_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "odvae_conv3x3_wgrad_f32": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
@@ -57,6 +59,7 @@ PROTOTYPES = {
     "odvae_groupnorm_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_fwd_partials_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _I, _P]),
     "odvae_groupnorm_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "odvae_groupnorm_bwd_partials_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "odvae_groupnorm_select_backward": (_I, [_I]),
     "odvae_groupnorm_fused_timeouts": (_I, []),
     "odvae_softmax_rows_f32": (_I, [_P, _P, _L, _I, _F, _P]),

@@ -257,6 +257,8 @@ UPCONV_BY_PARITY = os.environ.get("ODVAE_UPCONV_DENSE", "0") != "1"
 # Upsample conv forward / data gradient on the F(4x4,3x3) kernel where the OUTPUT shape qualifies (2.25 instead of 4 multiply-adds per output
 # pixel; the weight gradient stays on the parity-class kernel); ODVAE_UPCONV_WINOGRAD4=0 keeps modes 5 / 6
 UPCONV_WINOGRAD4 = os.environ.get("ODVAE_UPCONV_WINOGRAD4", "1") != "0"
+# ... and its data gradient 2x2-summed inside the F(4x4) output transform (odvae_conv3x3_wino4_pool_f32); ODVAE_UPCONV_POOLED_DGRAD=0: two steps
+UPCONV_POOLED_DGRAD = os.environ.get("ODVAE_UPCONV_POOLED_DGRAD", "1") != "0"
 
 
 def _conv3x3_raw(mode, x, pack, cin, cout, bias, residual, act=0):
@@ -317,6 +319,40 @@ GN_FUSED_STATS = os.environ.get("ODVAE_GN_FUSED_STATS", "1") != "0"
 GN_GROUPS = 32      # Normalize() of the reference model: GroupNorm(32, C, eps 1e-6)
 
 
+# First pass of a GroupNorm's backward (per-channel sums of du * xhat and du) from the epilogue of the data-gradient launch that produces
+# its dy: the conv that reads a = swish(GroupNorm(x)) finds the link the GroupNorm left on `a`, its backward runs
+# odvae_conv3x3_wino4_gnbwd_f32 and leaves the sums in the link; the GroupNorm's backward then skips gn_bwd_reduce_kernel (one read of x
+# and of dy less).  ODVAE_GN_FUSED_BWD=0 turns it off.
+GN_FUSED_BWD = os.environ.get("ODVAE_GN_FUSED_BWD", "1") != "0"
+GN_FUSED_BWD_HITS = 0      # GroupNorm backwards that ran without their reduce pass (diagnostics, tests)
+
+
+class _GnBwdLink:
+    """What the consumer conv's data gradient needs of the GroupNorm in front of it, and where it leaves the sums.  `out` identifies the
+    GroupNorm's output the way _gn_partials identifies a conv's: (data_ptr, version, shape)."""
+    __slots__ = ("x", "mean", "rstd", "gamma", "beta", "groups", "out", "sums")
+
+    def __init__(self):
+        self.x = self.mean = self.rstd = self.gamma = self.beta = self.out = self.sums = None
+        self.groups = 0
+
+    def take_sums(self, dy):
+        """The sums, if they were made from exactly this gradient tensor (else None); single use."""
+        sums, self.sums = self.sums, None
+        if sums is None:
+            return None
+        p, ptr, version, shape = sums
+        return p if (ptr == dy.data_ptr() and version == dy._version and shape == tuple(dy.shape)) else None
+
+
+def _gn_bwd_link_of(a, cin):
+    """The link a swish-GroupNorm left on this very tensor (f32, 32 groups), if `a` still holds that GroupNorm's output."""
+    link = getattr(a, "_gn_bwd_link", None)
+    if link is None or not GN_FUSED_BWD or link.out != (a.data_ptr(), a._version, tuple(a.shape)) or a.shape[1] != cin:
+        return None
+    return link
+
+
 def _gn_stats_ok(cout):
     cpg = cout // GN_GROUPS
     return GN_FUSED_STATS and cout % GN_GROUPS == 0 and 1 <= cpg <= 32 and (cpg & (cpg - 1)) == 0
@@ -356,9 +392,9 @@ class _Conv3x3(Function):
     """mode 0: stride 1 pad 1; mode 1: Downsample (pad (0,1,0,1), stride 2); mode 2: Upsample (nearest 2x) + conv."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, mode, relu, gn_stats=False):
+    def forward(ctx, x, weight, bias, residual, mode, relu, gn_stats=False, gn_link=None):
         """gn_stats=True: returns (y, partials) when the F(4x4) kernel takes the layer (partials: GroupNorm statistics of y per output
-        tile, not differentiable), (y, None) otherwise."""
+        tile, not differentiable), (y, None) otherwise.  gn_link: x is swish(GroupNorm(.)) and this is its link (_GnBwdLink)."""
         x = _cl(x)
         res = _cl(residual) if residual is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
@@ -384,6 +420,7 @@ class _Conv3x3(Function):
         else:
             y = _conv3x3_raw(5 if up else mode, x, fwd_pack, cin, cout, b, res, act=1 if relu else 0)
         ctx.mode, ctx.up = mode, up
+        ctx.gn_link = gn_link if (up == "wino4" and gn_link is not None and ctx.needs_input_grad[0]) else None
         ctx.pack_epoch = PACK_CACHE.epoch
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
@@ -413,10 +450,30 @@ class _Conv3x3(Function):
         if ctx.needs_input_grad[0]:
             PACK_CACHE.check_epoch(ctx.pack_epoch, "conv3x3 backward")
             _, dgr = pack_conv3x3(weight, False, True, "wino4" if ctx.up == "wino4up" else ctx.up)
-            if ctx.up == "wino4up":     # gradient w.r.t. the upsampled image on the F(4x4) kernel, then its 2x2 sum-pool
+            if ctx.up == "wino4up" and UPCONV_POOLED_DGRAD:
+                # gradient w.r.t. the upsampled image on the F(4x4) kernel, 2x2-summed in its output transform (never stored at full size)
+                dx = _new_cl(n, cin, hi, wi, x)
+                tag = KERNEL_EVENTS.begin()
+                _lib.check(L.odvae_conv3x3_wino4_pool_f32(dy.data_ptr(), n, ho, wo, cout, dgr.data_ptr(), cin, dx.data_ptr(), _lib.stream_ptr()),
+                           "conv3x3_wino4_pool")
+                KERNEL_EVENTS.end("conv3x3_wino4", 2.0 * 9 * cin * cout * n * ho * wo, tag, 4.0 * (n * ho * wo * cout + n * hi * wi * cin + 9 * cin * cout),
+                                  issued=2.0 * 2.25 * cin * cout * n * ho * wo)
+            elif ctx.up == "wino4up":   # the same in two steps: full-resolution gradient, then its 2x2 sum-pool
                 du = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=True)
                 dx = _new_cl(n, cin, hi, wi, x)
                 _lib.check(L.odvae_upsample2x_bwd_f32(du.data_ptr(), dx.data_ptr(), n, hi, wi, cin, _lib.stream_ptr()), "upsample2x_bwd")
+            elif ctx.up == "wino4" and ctx.gn_link is not None:
+                # da and, from the same output transform, the first pass of the backward of the GroupNorm that produced this conv's input
+                lk = ctx.gn_link
+                dx = _new_cl(n, cin, hi, wi, x)
+                sums = torch.empty(n, L.odvae_conv3x3_wino4_stats_chunks(hi, wi), 2, cin, dtype=torch.float32, device=x.device)
+                tag = KERNEL_EVENTS.begin()
+                _lib.check(L.odvae_conv3x3_wino4_gnbwd_f32(dy.data_ptr(), n, hi, wi, cout, dgr.data_ptr(), cin, dx.data_ptr(), lk.x.data_ptr(),
+                                                           lk.mean.data_ptr(), lk.rstd.data_ptr(), lk.gamma.data_ptr(), lk.beta.data_ptr(),
+                                                           lk.groups, sums.data_ptr(), _lib.stream_ptr()), "conv3x3_wino4_gnbwd")
+                KERNEL_EVENTS.end("conv3x3_wino4", 2.0 * 9 * cin * cout * n * hi * wi, tag, 4.0 * (n * hi * wi * (cin + cout) + 9 * cin * cout),
+                                  issued=2.0 * 2.25 * cin * cout * n * hi * wi)
+                lk.sums = (sums, dx.data_ptr(), dx._version, tuple(dx.shape))
             elif ctx.up in ("wino", "wino4"):
                 dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=ctx.up == "wino4")
             elif mode == 0:
@@ -453,7 +510,7 @@ class _Conv3x3(Function):
                 KERNEL_EVENTS.end("conv3x3_wgrad", 2.0 * 9 * cin * cout * n * ho * wo, None,
                                   issued=_conv_issued(wmode, n, hi, wi, ho, wo, cin, cout))
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=False, gn_stats=False):
@@ -471,14 +528,15 @@ def conv3x3(x, weight, bias=None, residual=None, mode=0, relu=False, out_f32=Fal
                 y._gn_partials = (partial, y.data_ptr(), y._version, tuple(y.shape))
             return y
         return _ConvB.apply(x, weight, bias, residual, mode, bool(out_f32))
+    link = _gn_bwd_link_of(x, weight.shape[1]) if (mode == 0 and not relu) else None
     if gn_stats and not relu and mode in (0, 2):
-        y, partial = _Conv3x3.apply(x, weight, bias, residual, mode, relu, True)
+        y, partial = _Conv3x3.apply(x, weight, bias, residual, mode, relu, True, link)
         if partial is not None:
             # the statistics are valid for exactly these values: the tag (storage, version counter, shape) lets the consumer tell
             # whether anything wrote to the tensor in between (an in-place op, a hook, a checkpoint wrapper's copy)
             y._gn_partials = (partial, y.data_ptr(), y._version, tuple(y.shape))
         return y
-    return _Conv3x3.apply(x, weight, bias, residual, mode, relu)
+    return _Conv3x3.apply(x, weight, bias, residual, mode, relu, False, link)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -707,9 +765,9 @@ def attention_qkv(qkv):
 # ------------------------------------------------------------------------------------------------------
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False, partials=None):
+    def forward(ctx, x, gamma, beta, groups, eps, swish, with_skip=False, partials=None, link=None):
         """partials [N][chunks][groups][2]: the statistics of x as the conv that produced it left them (ops.conv3x3(gn_stats=True)):
-        no statistics pass."""
+        no statistics pass.  link (_GnBwdLink, swish only): filled here for the conv that reads the result (GN_FUSED_BWD)."""
         L = _L()
         x = _cl(x)
         n, c, h, w = x.shape
@@ -733,6 +791,10 @@ class _GroupNorm(Function):
         ctx.groups, ctx.swish = groups, int(swish)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.set_materialize_grads(False)   # an unused output's gradient stays None instead of a tensor of zeros
+        ctx.link = None
+        if link is not None and swish:
+            link.x, link.mean, link.rstd, link.gamma, link.beta, link.groups = x.detach(), mean, rstd, g, b, groups
+            ctx.link = link
         if with_skip:
             return y, x.view_as(x)   # the skip connection's handle on x: its gradient comes back into this node
         return y
@@ -742,8 +804,9 @@ class _GroupNorm(Function):
         L = _L()
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if dy is None:               # only the skip branch carried a gradient
-            return dskip, None, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None, None
         dy = _cl(dy)
+        sums = ctx.link.take_sums(dy) if ctx.link is not None else None
         if dskip is not None:
             dskip = _cl(dskip)
         n, c, h, w = x.shape
@@ -754,13 +817,21 @@ class _GroupNorm(Function):
         b = beta.detach().contiguous()
         wp, wn = _ws(L.odvae_groupnorm_workspace_bytes(n, h * w, c, ctx.groups), x)
         tag = KERNEL_EVENTS.begin(secondary=True)
-        _lib.check(L.odvae_groupnorm_bwd_f32(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(),
-                                             b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(),
-                                             dg.data_ptr(), db.data_ptr(), _lib.ptr(dskip), wp, wn, _lib.stream_ptr()),
-                   "groupnorm_bwd")
+        if sums is not None:         # the data-gradient launch that made dy left the first pass's sums: finalize + apply only
+            global GN_FUSED_BWD_HITS
+            GN_FUSED_BWD_HITS += 1
+            _lib.check(L.odvae_groupnorm_bwd_partials_f32(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(),
+                                                          b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(),
+                                                          dg.data_ptr(), db.data_ptr(), _lib.ptr(dskip), sums.data_ptr(), int(sums.shape[1]),
+                                                          wp, wn, _lib.stream_ptr()), "groupnorm_bwd_partials")
+        else:
+            _lib.check(L.odvae_groupnorm_bwd_f32(x.data_ptr(), dy.data_ptr(), n, h * w, c, ctx.groups, g.data_ptr(),
+                                                 b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ctx.swish, dx.data_ptr(),
+                                                 dg.data_ptr(), db.data_ptr(), _lib.ptr(dskip), wp, wn, _lib.stream_ptr()),
+                       "groupnorm_bwd")
         # algorithmic traffic: x, dy (and the folded skip gradient) read once, dx written once
         KERNEL_EVENTS.end("groupnorm", 0.0, tag, 4.0 * (3 + (dskip is not None)) * n * h * w * c, issued=0.0)
-        return dx, dg, db, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None
 
 
 def _gn_partials_of(x, groups):
@@ -778,10 +849,22 @@ def _gn_partials_of(x, groups):
     return p
 
 
+def _f32_gn_link(x, groups, swish):
+    return _GnBwdLink() if (GN_FUSED_BWD and swish and groups == GN_GROUPS and torch.is_grad_enabled() and x.requires_grad) else None
+
+
+def _tag_gn_output(y, link):
+    if link is not None and link.x is not None:
+        link.out = (y.data_ptr(), y._version, tuple(y.shape))
+        y._gn_bwd_link = link
+    return y
+
+
 def group_norm(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     if x.dtype == BF16:
         return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, False, _gn_partials_of(x, groups))
-    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, False, _gn_partials_of(x, groups))
+    link = _f32_gn_link(x, groups, swish)
+    return _tag_gn_output(_GroupNorm.apply(x, gamma, beta, groups, eps, swish, False, _gn_partials_of(x, groups), link), link)
 
 
 def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
@@ -790,7 +873,9 @@ def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     autograd's separate 3-pass add)."""
     if x.dtype == BF16:
         return _GroupNormB.apply(x, gamma, beta, groups, eps, swish, True, _gn_partials_of(x, groups))
-    return _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True, _gn_partials_of(x, groups))
+    link = _f32_gn_link(x, groups, swish)
+    y, skip = _GroupNorm.apply(x, gamma, beta, groups, eps, swish, True, _gn_partials_of(x, groups), link)
+    return _tag_gn_output(y, link), skip
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -120,6 +120,18 @@ int odvae_conv3x3_wino4_stats_f32(const float* x, int N, int H, int W, int Cin, 
  * odvae_conv3x3_wino4_supported(H, W, Cin, Cout) on the OUTPUT size. */
 int odvae_conv3x3_wino4_up_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout, const float* bias,
                                const float* residual, float* y, float* gn_partial, int gn_groups, void* stream);
+/* Data gradient of the Upsample conv w.r.t. its LOW-resolution input ([UPSTREAM] Upsample.forward: interpolate(2x, nearest), conv): x = the
+ * conv's dy [N][H][W][Cin], upk = its data-gradient pack, y [N][H/2][W/2][Cout] = the 2x2 sums of the full-resolution gradient, formed in the
+ * output transform (that gradient is never stored; odvae_upsample2x_bwd_f32 is not needed behind it). */
+int odvae_conv3x3_wino4_pool_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout, float* y, void* stream);
+/* Data gradient of a conv whose INPUT was a = swish(GroupNorm(gn_x)) ([UPSTREAM] ResnetBlock: `h = conv(nonlinearity(norm(h)))`), and the
+ * first pass of that GroupNorm's backward out of the same output transform: x = the conv's dy [N][H][W][Cin], upk = its data-gradient
+ * pack, y = da [N][H][W][Cout]; gn_partial [N][odvae_conv3x3_wino4_stats_chunks(H, W)][2][Cout] = per output tile and channel
+ * (sum du * xhat, sum du), du = da * swish'(xhat * gamma + beta) -- every slot written by exactly one block.  Feed it to
+ * odvae_groupnorm_bwd_partials_f32: da and gn_x are then not streamed a second time for the sums. */
+int odvae_conv3x3_wino4_gnbwd_f32(const float* x, int N, int H, int W, int Cin, const float* upk, int Cout, float* y,
+                                  const float* gn_x, const float* gn_mean, const float* gn_rstd, const float* gn_gamma, const float* gn_beta,
+                                  int gn_groups, float* gn_partial, void* stream);
 
 /* ---- conv3x3_wgrad_f32.hip: weight/bias gradient autograd computes for those convolutions (modes 0-2; mode 5 =
  * mode 2 accumulated per output parity class, 16 instead of 36 tap-products per input pixel, same dw)
@@ -155,6 +167,12 @@ int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int 
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
                             float* dx, float* dgamma, float* dbeta, const float* dx_add,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* the same with the sums of the first pass given: partial [N][chunks][2][C] as odvae_conv3x3_wino4_gnbwd_f32 leaves it; finalize (f64,
+ * fixed order) + apply.  workspace: (N * 2 * C + N * G * 2) floats (odvae_groupnorm_workspace_bytes covers it). */
+int odvae_groupnorm_bwd_partials_f32(const float* x, const float* dy, int N, int HW, int C, int G,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
+                                     float* dx, float* dgamma, float* dbeta, const float* dx_add, const float* partial, int chunks,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 /* backward form of odvae_groupnorm_bwd_f32: -1 (default) the read-once kernel where ONE block holds a (sample, 32-channel slab) in its
  * registers (HW <= 256; C % 32 == 0, whole groups per slab), reduce + apply (x and dy read twice) elsewhere; 0 always reduce + apply;
  * 1 the read-once kernel on every shape it takes (teams of ceil(HW / 256) resident blocks that meet at a per-item barrier in L2 --

@@ -319,6 +319,65 @@ def test_groupnorm_statistics_from_the_conv_epilogue(hip_lib, monkeypatch, n, ci
         assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item(), what
 
 
+@pytest.mark.parametrize("n,c,cout,h,w,skip", [(2, 64, 64, 16, 32, False), (3, 128, 64, 48, 64, True), (1, 256, 128, 20, 36, True),
+                                               (2, 64, 128, 32, 32, False)])
+def test_groupnorm_backward_sums_from_the_conv_data_gradient(hip_lib, monkeypatch, n, c, cout, h, w, skip):
+    """conv3x3(swish(GroupNorm(x))): the conv's data-gradient launch (F(4x4)) also leaves the per-channel sums of the GroupNorm's
+    backward (odvae_conv3x3_wino4_gnbwd_f32 -> odvae_groupnorm_bwd_partials_f32), so the GroupNorm's reduce pass does not run.  Against
+    torch CPU and against the same graph with the fusion off; ragged tiles, three images, Cin != Cout, a skip gradient folded in."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD4", True)
+    g = torch.Generator().manual_seed(c + h + n)
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3
+    wt = torch.randn(cout, c, 3, 3, generator=g) / (3.0 * c ** 0.5)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g)
+    gs = torch.randn(n, c, h, w, generator=g)
+    xr, wr, gr, br = (t.clone().requires_grad_(True) for t in (x, wt, gamma, beta))
+    ref = F.conv2d(F.silu(F.group_norm(xr, 32, gr, br, eps=1e-6)), wr, None, padding=1)
+    (ref * gy).sum().backward() if not skip else ((ref * gy).sum() + (xr * gs).sum()).backward()
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "GN_FUSED_BWD", fused)
+        hits = ops.GN_FUSED_BWD_HITS
+        xd, wd, gd, bd = (t.to(dev()).requires_grad_(True) for t in (x, wt, gamma, beta))
+        xin = xd.contiguous(memory_format=torch.channels_last)
+        if skip:
+            a, xs = ops.group_norm_skip(xin, gd, bd, 32, 1e-6, swish=True)
+        else:
+            a, xs = ops.group_norm(xin, gd, bd, 32, 1e-6, swish=True), None
+        y = ops.conv3x3(a, wd, None, None)
+        loss = (y * gy.to(dev())).sum() + ((xs * gs.to(dev())).sum() if skip else 0.0)
+        loss.backward()
+        assert (ops.GN_FUSED_BWD_HITS - hits) == (1 if fused else 0)
+        outs[fused] = (y.detach(), xd.grad, wd.grad, gd.grad, bd.grad)
+    for got, other, want, what in zip(outs[True], outs[False], (ref, xr.grad, wr.grad, gr.grad, br.grad), ("y", "dx", "dw", "dgamma", "dbeta")):
+        close(got, want, 5e-4 if what in ("y", "dx") else BWD_TOL * 4, "GroupNorm backward sums from the data gradient: " + what)
+        assert (got - other).abs().max().item() <= 3e-5 * max(1.0, other.abs().max().item()), what + " vs the two-kernel form"
+
+
+def test_groupnorm_backward_sums_are_not_used_for_another_gradient(hip_lib, monkeypatch):
+    """Two consumers of swish(GroupNorm(x)): autograd sums their gradients into a new tensor, which is not the one the first conv's data
+    gradient made its sums from -- the GroupNorm must run its own reduce pass."""
+    from odvae_amd import ops
+    monkeypatch.setattr(ops, "WINOGRAD4", True)
+    monkeypatch.setattr(ops, "GN_FUSED_BWD", True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 16, 32, generator=g)
+    wt = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    gamma, beta = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    ar = F.silu(F.group_norm(xr, 32, gr, br, eps=1e-6))
+    (F.conv2d(ar, wt, None, padding=1).sum() + (ar * ar).sum()).backward()
+    xd, gd, bd = (t.to(dev()).requires_grad_(True) for t in (x, gamma, beta))
+    hits = ops.GN_FUSED_BWD_HITS
+    a = ops.group_norm(xd.contiguous(memory_format=torch.channels_last), gd, bd, 32, 1e-6, swish=True)
+    (ops.conv3x3(a, wt.to(dev()), None, None).sum() + (a * a).sum()).backward()
+    assert ops.GN_FUSED_BWD_HITS == hits
+    close(xd.grad, xr.grad, 5e-4, "dx with two consumers")
+    close(gd.grad, gr.grad, BWD_TOL * 4, "dgamma with two consumers")
+
+
 def test_epilogue_statistics_are_dropped_when_the_tensor_was_written_to(hip_lib, monkeypatch):
     """The statistics ride on the conv's output tensor OBJECT, tagged with its storage pointer, version counter and shape.  An in-place
     write between the conv and the GroupNorm (a hook, a future fusion) changes the version: the GroupNorm must then take its own
@@ -623,12 +682,13 @@ def test_upsample_conv_on_the_f4x4_kernel(hip_lib, monkeypatch, n, cin, cout, h,
     y_ref = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, br, padding=1)
     y_ref.backward(gy)
     outs = {}
-    for f4 in (True, False):
-        monkeypatch.setattr(ops, "UPCONV_WINOGRAD4", f4)
+    for f4 in (True, "two-step", False):     # "two-step": full-resolution data gradient + odvae_upsample2x_bwd_f32 instead of the pooled epilogue
+        monkeypatch.setattr(ops, "UPCONV_WINOGRAD4", bool(f4))
+        monkeypatch.setattr(ops, "UPCONV_POOLED_DGRAD", f4 is True)
         xd, wd, bd = x.to(dev()).requires_grad_(True), wt.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
         y = ops.conv3x3(xd, wd, bd, None, mode=2, gn_stats=True)
         part = ops._gn_partials_of(y, 32)
-        assert (part is not None) == (f4 and cout % 32 == 0)
+        assert (part is not None) == (bool(f4) and cout % 32 == 0)
         if part is not None:
             yc = y.detach().double().cpu().reshape(n, 32, cout // 32, 4 * h * w)
             want = torch.stack([yc.sum(dim=(2, 3)), (yc * yc).sum(dim=(2, 3))], dim=-1)
@@ -638,6 +698,7 @@ def test_upsample_conv_on_the_f4x4_kernel(hip_lib, monkeypatch, n, cin, cout, h,
     for (a, c, ref, what) in zip(outs[True], outs[False], (y_ref, xr.grad, wr.grad, br.grad), ("y", "dx", "dw", "db")):
         close(a, ref, 5e-4 if what in ("y", "dx") else BWD_TOL * 4, "upsample conv on F(4x4): " + what)
         assert (a - c).abs().max().item() <= 6e-5 * max(1.0, c.abs().max().item()), what + " vs the parity-class kernels"
+    assert (outs[True][1] - outs["two-step"][1]).abs().max().item() <= 2e-6 * max(1.0, outs["two-step"][1].abs().max().item()), "pooled vs two-step dx"
 
 
 @pytest.mark.parametrize("n,cout,h,w", [(2, 3, 16, 32), (1, 3, 20, 36), (3, 2, 8, 8), (2, 3, 64, 96), (1, 1, 9, 33)])
