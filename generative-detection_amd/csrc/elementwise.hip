@@ -22,9 +22,14 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // ---- row softmax ---------------------------------------------------------------------------------
 // AttnBlock.forward: w_ = softmax(bmm(q,k) * C^-0.5, dim=keys)  ([UPSTREAM] ldm .../model.py AttnBlock)
 // one block per row; cols % 4 == 0.  y may alias x.
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, float* y, int64_t rows, int cols, float scale) {
+// pred (nullable): the launch does nothing unless *pred != 0; ones (nullable): ones[row] = 1 for every row done (the folded-softmax
+// fallback of ops.attention: the probabilities it writes are normalised, their row factor is 1)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, float* y, int64_t rows, int cols, float scale,
+                                                           const int* pred, float* ones) {
   __shared__ float sh[8];
+  if (pred && *pred == 0) return;
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    if (ones && threadIdx.x == 0) ones[row] = 1.f;
     const float* xr = x + row * cols;
     float* yr = y + row * cols;
     float mx = -INFINITY;
@@ -90,9 +95,12 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* p, c
 // Register-resident forms: the whole row (NV float4 per thread, cols <= 1024*NV) is read ONCE, reduced, and written
 // once: 2 HBM passes instead of 4 (forward) and 3 instead of 5 (backward).  Used whenever the row fits.
 template <int NV>
-__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* x, float* y, int64_t rows, int cols, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* x, float* y, int64_t rows, int cols, float scale,
+                                                               const int* pred, float* ones) {
   __shared__ float sh[8];
+  if (pred && *pred == 0) return;
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    if (ones && threadIdx.x == 0) ones[row] = 1.f;
     const float* xr = x + row * cols;
     float4 v[NV];
     float mx = -INFINITY;
@@ -488,17 +496,103 @@ int odvae_latent_combine_f32(const float* z, const float* mask, const float* add
   return ODVAE_OK;
 }
 
-int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, float scale, void* stream) {
+static int softmax_rows_impl(const float* x, float* y, int64_t rows, int cols, float scale, const int* pred, float* ones, void* stream) {
   ODVAE_CHECK_ARG(x && y && rows > 0 && cols > 0 && cols % 4 == 0, "softmax_rows: need cols %% 4 == 0 (rows=%lld cols=%d)", (long long)rows, cols);
   ODVAE_CHECK_ARG(scale > 0.f, "softmax_rows: scale must be positive");
-  const dim3 grid((unsigned)std::min<int64_t>(rows, 65536 * 4)), block(256);
+  // (under a predicate: a small grid that walks the rows, so that finding out there is nothing to do is a 2 048-block launch)
+  const dim3 grid((unsigned)std::min<int64_t>(rows, pred ? 2048 : 65536 * 4)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (cols <= 1024)       hipLaunchKernelGGL((softmax_rows_reg_kernel<1>), grid, block, 0, st, x, y, rows, cols, scale);
-  else if (cols <= 2048)  hipLaunchKernelGGL((softmax_rows_reg_kernel<2>), grid, block, 0, st, x, y, rows, cols, scale);
-  else if (cols <= 4096)  hipLaunchKernelGGL((softmax_rows_reg_kernel<4>), grid, block, 0, st, x, y, rows, cols, scale);
-  else if (cols <= 16384) hipLaunchKernelGGL((softmax_rows_reg_kernel<16>), grid, block, 0, st, x, y, rows, cols, scale);
-  else                    hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, st, x, y, rows, cols, scale);
+  if (cols <= 1024)       hipLaunchKernelGGL((softmax_rows_reg_kernel<1>), grid, block, 0, st, x, y, rows, cols, scale, pred, ones);
+  else if (cols <= 2048)  hipLaunchKernelGGL((softmax_rows_reg_kernel<2>), grid, block, 0, st, x, y, rows, cols, scale, pred, ones);
+  else if (cols <= 4096)  hipLaunchKernelGGL((softmax_rows_reg_kernel<4>), grid, block, 0, st, x, y, rows, cols, scale, pred, ones);
+  else if (cols <= 16384) hipLaunchKernelGGL((softmax_rows_reg_kernel<16>), grid, block, 0, st, x, y, rows, cols, scale, pred, ones);
+  else                    hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, st, x, y, rows, cols, scale, pred, ones);
   ODVAE_LAUNCH_CHECK("softmax_rows");
+  return ODVAE_OK;
+}
+
+int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, float scale, void* stream) {
+  return softmax_rows_impl(x, y, rows, cols, scale, nullptr, nullptr, stream);
+}
+
+// The same under a device-side predicate (nothing happens unless *pred != 0), also writing ones[row] = 1: the fallback of the folded
+// attention softmax (odvae_gemm_exp_bound_f32 / odvae_gemm_rownorm_f32) where a row's bound was too loose.
+int odvae_softmax_rows_pred_f32(const float* x, float* y, int64_t rows, int cols, float scale, const int* pred, float* ones, void* stream) {
+  ODVAE_CHECK_ARG(pred && ones, "softmax_rows_pred: null predicate / row-factor array");
+  return softmax_rows_impl(x, y, rows, cols, scale, pred, ones, stream);
+}
+
+// ---- folded attention softmax: the per-row bound of the scores, and the backward's row dot product with dO / l beside it ----
+// qkv [rows][3C] (q | k | v per token).  nq[row] = |q_row|, nk[row] = |k_row|: one wavefront per token.
+__global__ __launch_bounds__(256) void attn_rownorm_kernel(const float* __restrict__ qkv, int64_t rows, int C,
+                                                           float* __restrict__ nq, float* __restrict__ nk) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const float4* pq = reinterpret_cast<const float4*>(qkv + row * 3 * C);
+    const float4* pk = reinterpret_cast<const float4*>(qkv + row * 3 * C + C);
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < C / 4; i += 64) {
+      const float4 x = pq[i], y = pk[i];
+      a += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      b += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) { nq[row] = sqrtf(a); nk[row] = sqrtf(b); }
+  }
+}
+// one block per image: bound[i] = |q_i| * max_j |k_j| (>= q_i . k_j for every j, Cauchy-Schwarz; a hair above for the rounding of the
+// norms), in place over nq; block 0 clears the fallback flag
+__global__ __launch_bounds__(256) void attn_bound_kernel(float* __restrict__ nq, const float* __restrict__ nk, int T, int* flag) {
+  __shared__ float sh[4];
+  const int n = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < T; i += 256) m = fmaxf(m, nk[(int64_t)n * T + i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) * 1.000001f;
+  for (int i = threadIdx.x; i < T; i += 256) nq[(int64_t)n * T + i] *= m;
+  if (n == 0 && threadIdx.x == 0 && flag) *flag = 0;
+}
+
+// out[row] = a[row] . b[row] and as[row][:] = a[row][:] * rs[row]  (attention backward with P = E / l: D_i = dO_i . O_i, dO_i / l_i)
+__global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ rs,
+                                                           int64_t rows, int cols, float* __restrict__ out, float* __restrict__ as) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const float4* pa = reinterpret_cast<const float4*>(a + row * cols);
+    const float4* pb = reinterpret_cast<const float4*>(b + row * cols);
+    float4* po = reinterpret_cast<float4*>(as + row * cols);
+    const float r = rs[row];
+    float s = 0.f;
+    for (int q = lane; q < cols / 4; q += 64) {
+      const float4 x = pa[q], y = pb[q];
+      s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      po[q] = make_float4(x.x * r, x.y * r, x.z * r, x.w * r);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+  }
+}
+
+// bound[N * T] for odvae_gemm_exp_bound_f32 from qkv [N][T][3C]; nk_scratch [N * T]; *flag (nullable) is cleared
+int odvae_attn_row_bound_f32(const float* qkv, int N, int T, int C, float* bound, float* nk_scratch, int* flag, void* stream) {
+  ODVAE_CHECK_ARG(qkv && bound && nk_scratch && N > 0 && T > 0 && C > 0 && C % 4 == 0, "attn_row_bound: bad arguments (C %% 4 == 0 needed)");
+  ODVAE_CHECK_ARG(((uintptr_t)qkv & 15) == 0, "attn_row_bound: qkv must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)N * T;
+  hipLaunchKernelGGL(attn_rownorm_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(rows, 4), 65536)), dim3(256), 0, st, qkv, rows, C, bound, nk_scratch);
+  ODVAE_LAUNCH_CHECK("attn_rownorm");
+  hipLaunchKernelGGL(attn_bound_kernel, dim3(N), dim3(256), 0, st, bound, nk_scratch, T, flag);
+  ODVAE_LAUNCH_CHECK("attn_bound");
+  return ODVAE_OK;
+}
+
+int odvae_rowdot_scale_f32(const float* a, const float* b, const float* row_scale, int64_t rows, int cols, float* out, float* a_scaled, void* stream) {
+  ODVAE_CHECK_ARG(a && b && row_scale && out && a_scaled && rows > 0 && cols > 0 && cols % 4 == 0, "rowdot_scale: need cols %% 4 == 0");
+  const dim3 grid((unsigned)std::min<int64_t>(ceil_div64(rows, 4), 65536)), block(256);
+  hipLaunchKernelGGL(rowdot_scale_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a, b, row_scale, rows, cols, out, a_scaled);
+  ODVAE_LAUNCH_CHECK("rowdot_scale");
   return ODVAE_OK;
 }
 

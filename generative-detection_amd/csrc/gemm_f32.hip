@@ -53,9 +53,17 @@ struct GemmParams {
   float alpha;
   int splits, k_per_split;
   int tiles_m;
-  // softmax-backward epilogue (SMB kernels only): C = alpha * emul .* (A B^T - rowsub[row]); emul has C's layout
+  // softmax-backward epilogue (EPI_SMB kernels only): C = alpha * emul .* (A B^T - rowsub[row]) (* rowmul[row]); emul has C's layout
   const float* rowsub; const float* emul; int64_t sRow;
+  const float* rowmul;   // EPI_SMB: optional second row factor (1 / l_i when emul holds unnormalised exponentials), or null
+  // EPI_EXPB: C = exp(alpha * (A B^T - rowsub[row])) -- attention scores leave the QK^T product as exponentials relative to a per-row
+  //           upper bound of the scores instead of the row maximum: no separate softmax pass over the T x T tensor
+  // EPI_ROWNORM (A k-contiguous, unsplit): l[row] = sum_k A[row][k] is accumulated beside the products, C = A B / l[row];
+  //           rowout[row] = 1 / l[row] (written by the first column tile); *flag |= 1 where l is not a normal number >= 1e-30
+  float* rowout; int* flag;
+  const int* pred;       // gemm_f32_pred_kernel: nothing happens unless *pred != 0
 };
+constexpr int EPI_NONE = 0, EPI_SMB = 1, EPI_EXPB = 2, EPI_ROWNORM = 3;
 
 // Operand tiles are fetched through a buffer descriptor that starts at the tile's origin (first row of the block, first k of
 // the split): the per-lane byte offsets are computed once, a step only changes a scalar offset, and rows / k beyond the
@@ -185,33 +193,48 @@ __device__ __forceinline__ void read_frag(const float* S, int row, int g, int h,
   }
 }
 
-template <bool A_KC, bool B_KC, bool SMB, int DMA>     // DMA: 0 register-staged, else the step width of the LDS-DMA form
-__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem);
+template <bool A_KC, bool B_KC, int EPI, int DMA>     // DMA: 0 register-staged, else the step width of the LDS-DMA form
+__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int tile, int batch);
 
 // LDS-DMA form: 64 KB of dynamic LDS and two blocks per CU at BKT = 32, 32 KB and four at BKT = 16
-template <bool A_KC, bool B_KC, bool SMB = false, int BKT = 32>
-__global__ __launch_bounds__(256, BKT == 32 ? 2 : (SMB ? 2 : 4)) void gemm_f32_dma_kernel(GemmParams p) {
+template <bool A_KC, bool B_KC, int EPI = EPI_NONE, int BKT = 32>
+__global__ __launch_bounds__(256, BKT == 32 ? 2 : (EPI == EPI_SMB ? 2 : 4)) void gemm_f32_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  gemm_body<A_KC, B_KC, SMB, BKT>(p, dsm);
+  gemm_body<A_KC, B_KC, EPI, BKT>(p, dsm, blockIdx.x, blockIdx.z);
 }
 
-template <bool A_KC, bool B_KC, bool SMB = false, bool OCC3 = (A_KC && B_KC && !SMB)>
+template <bool A_KC, bool B_KC, int EPI = EPI_NONE, bool OCC3 = (A_KC && B_KC && EPI != EPI_SMB)>
 // OCC3: three blocks per CU (150 registers, the accumulators in VGPRs).  The form with both operands k-contiguous (QK^T-shaped
 // and 1x1-forward products) gains 4-6 % from the third block covering prologue / store bursts, the unsplit batched TN products
 // of the attention backward 3 %; the NN form and the split-K weight-gradient shapes lose 3-10 % with it and stay at two
 // (tools/gemm_probe.py).
 __global__ __launch_bounds__(256, OCC3 ? 3 : 1) void gemm_f32_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
-  gemm_body<A_KC, B_KC, SMB, 0>(p, smem);
+  gemm_body<A_KC, B_KC, EPI, 0>(p, smem, blockIdx.x, blockIdx.z);
 }
 
-template <bool A_KC, bool B_KC, bool SMB, int DMA>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
+// The plain product under a device-side predicate, as ONE small grid: nothing happens unless *p.pred != 0 -- then the resident blocks walk
+// the (tile, batch) pairs.  (A predicate inside gemm_f32_kernel would cost a 32 768-block launch ~50 us to find out it has nothing to do;
+// here the no-op is a 1 024-block launch.)  The fallback of the folded attention softmax; unsplit shapes.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_pred_kernel(GemmParams p, int tiles, int batches) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+  if (*p.pred == 0) return;
+  for (int t = blockIdx.x; t < tiles * batches; t += gridDim.x) {
+    gemm_body<A_KC, B_KC, EPI_NONE, 0>(p, smem, t % tiles, t / tiles);
+    __syncthreads();      // the next pair's first tile stores must not overtake this pair's last fragment reads
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI, int DMA>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int tile, int batch) {
+  constexpr bool SMB = EPI == EPI_SMB, EXPB = EPI == EPI_EXPB, ROWNORM = EPI == EPI_ROWNORM;
+  static_assert(!ROWNORM || (A_KC && DMA == 0), "the row-sum form is built on the register-staged loop with A k-contiguous");
   float* As = smem;
   float* Bs = smem + TILE_FLOATS;
 
-  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
-  const int split = blockIdx.y, batch = blockIdx.z;
+  const int tile_m = tile % p.tiles_m, tile_n = tile / p.tiles_m;
+  const int split = blockIdx.y;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = split * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
@@ -245,15 +268,25 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
   };
 
   f32x16 acc[2][2];
-  if constexpr (SMB) {   // accumulators start at -rowsub[row]: the products then add up to dP - D
-    const float* rs = p.rowsub + batch * p.sRow + m0;
+  // per-row vectors (rowsub, rowmul) of this tile: buffer loads whose descriptor ends at the tile's last row -- rows past it read 0, no
+  // guard (32 guarded loads per lane, each waited for on its own, cost ~4 us per block: 8 % of a QK^T-shaped tile)
+  float rmv[2][16];      // SMB: rowmul[row] (or 1)
+  if constexpr (SMB || EXPB) {   // accumulators start at -rowsub[row]: the products then add up to dP - D (EXPB: to s - bound)
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.rowsub) + batch * p.sRow + m0, 0, rows_here * 4, 0x00020000);
+    const bool has_mul = SMB && p.rowmul != nullptr;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_mul ? p.rowmul : p.rowsub) + batch * p.sRow + m0, 0, has_mul ? rows_here * 4 : 0, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 64 + mt * 32 + acc_row(r, lane);
-        const float d = row < rows_here ? -rs[row] : 0.f;
+        const float d = -__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srs, row * 4, 0, 0));
         acc[mt][0][r] = d; acc[mt][1][r] = d;
+        if constexpr (SMB) {
+          const float m = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrs, row * 4, 0, 0));
+          rmv[mt][r] = has_mul ? m : 1.f;
+        }
       }
   } else if (!to_partial && p.residual) {
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -276,6 +309,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
 
+  float rowl[2] = {0.f, 0.f};      // ROWNORM: this lane's share of the sums of rows wm * 64 + {0, 32} + li
   if constexpr (DMA != 0) {
     // One barrier per step: the tiles of step s+1 are requested (LDS-DMA, inline asm: invisible to hipcc's vmcnt bookkeeping, awaited by
     // hand) into the other stage at the top of step s and have its MFMAs to land.  Fragment addresses: one VGPR per (operand, k group)
@@ -371,6 +405,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
         read_frag<A_KC>(As, wm * 64 + t * 32 + li, g, h, a[t]);
         read_frag<B_KC>(Bs, wn * 64 + t * 32 + li, g, h, b[t]);
       }
+      if constexpr (ROWNORM) {      // this lane's share of row li's sum: k = 8g + 4h + j (zero past K: out-of-range k reads as 0)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) rowl[t] += (a[t][0] + a[t][1]) + (a[t][2] + a[t][3]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -394,6 +432,45 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
   for (int nt = 0; nt < 2; ++nt)
     bv[nt] = (!to_partial && p.bias) ? p.bias[min(n0 + wn * 64 + nt * 32 + li, p.N - 1)] : 0.f;
   const float alpha = to_partial ? 1.f : p.alpha;
+  if constexpr (EXPB) {  // exponentials of (score - row bound): exp2 of one product
+    const float a2 = alpha * 1.44269504088896f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rb_ = row_byte(mt, r);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_exp2f(acc[mt][nt][r] * a2)), crsrc, rb_ + colbyte[nt], 0, 0);
+      }
+    return;
+  }
+  if constexpr (ROWNORM) {
+    // row sums: the two lane halves hold the k classes 4h .. 4h + 3 of every group of 8; the wn = 0 waves publish them in LDS (the
+    // operand tiles are dead: the loop ended on a barrier), every lane then picks up the rows its accumulator registers hold
+    float* rl = smem;      // [128]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) rowl[t] += __shfl_xor(rowl[t], 32, 64);
+    if (wn == 0 && h == 0) { rl[wm * 64 + li] = rowl[0]; rl[wm * 64 + 32 + li] = rowl[1]; }
+    __syncthreads();
+    bool bad = false;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mt * 32 + acc_row(r, lane);
+        const float l = rl[row];
+        const float rinv = 1.f / l;
+        bad |= row < rows_here && !(l >= 1e-30f && l < 3.0e38f);
+        const unsigned rb_ = row_byte(mt, r);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * rinv), crsrc, rb_ + colbyte[nt], 0, 0);
+        if (tile_n == 0 && wn == 0 && li == 0 && row < rows_here) p.rowout[batch * p.sRow + m0 + row] = rinv;
+      }
+    if (p.flag && __any(bad) && lane == 0) atomicOr(p.flag, 1);
+    return;
+  }
   if constexpr (SMB) {   // all loads of the multiplier tile first, then stores only
     const __amdgpu_buffer_rsrc_t ersrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.emul) + batch * p.sC + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
@@ -414,7 +491,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem) {
         const unsigned rb_ = row_byte(mt, r);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * alpha * pv[mt][nt][r]), crsrc, rb_ + colbyte[nt], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * (alpha * rmv[mt][r]) * pv[mt][nt][r]), crsrc, rb_ + colbyte[nt], 0, 0);
       }
     return;
   }
@@ -499,12 +576,64 @@ size_t odvae_gemm_f32_workspace_bytes(int M, int N, int K, int batch) {
   return s > 1 ? (size_t)s * batch * M * N * sizeof(float) : 0;
 }
 
+static int gemm_f32_impl(int transA, int transB, int M, int N, int K, float alpha,
+                         const float* A, int lda, int64_t strideA,
+                         const float* B, int ldb, int64_t strideB,
+                         float* C, int ldc, int64_t strideC,
+                         const float* bias, const float* residual, int batch,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
                    const float* A, int lda, int64_t strideA,
                    const float* B, int ldb, int64_t strideB,
                    float* C, int ldc, int64_t strideC,
                    const float* bias, const float* residual, int batch,
                    void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_f32_impl(transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, bias, residual, batch,
+                       workspace, workspace_bytes, stream);
+}
+
+// The same launch under a device-side predicate: every block returns at once unless *pred != 0 (the fallback products of
+// odvae_attention_fwd_f32's folded softmax; unsplit shapes only).
+int odvae_gemm_pred_f32(int transA, int transB, int M, int N, int K, float alpha,
+                        const float* A, int lda, int64_t strideA,
+                        const float* B, int ldb, int64_t strideB,
+                        float* C, int ldc, int64_t strideC, int batch, const int* pred, void* stream) {
+  ODVAE_CHECK_ARG(pred, "gemm_pred: null predicate");
+  ODVAE_CHECK_ARG(odvae_gemm_f32_workspace_bytes(M, N, K, batch) == 0, "gemm_pred: split-K shapes are not offered (M=%d N=%d K=%d batch=%d)", M, N, K, batch);
+  ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && A && B && C, "gemm_pred: bad arguments");
+  ODVAE_CHECK_ARG((int64_t)BM * ldc * 4 < 0x7FFFFFF0ll, "gemm_pred: ldc %d too large for 32-bit tile offsets", ldc);
+  ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0, "gemm_pred: lda/ldb/strides must be multiples of 4 floats");
+  ODVAE_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_pred: A/B must be 16-byte aligned");
+  if (!transA || transB) ODVAE_CHECK_ARG(K % 4 == 0, "gemm_pred: a k-contiguous operand needs K %% 4 == 0 (K=%d)", K);
+  if (transA) ODVAE_CHECK_ARG(M % 4 == 0, "gemm_pred: transA needs M %% 4 == 0 (M=%d)", M);
+  if (!transB) ODVAE_CHECK_ARG(N % 4 == 0, "gemm_pred: transB=0 needs N %% 4 == 0 (N=%d)", N);
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.residual = nullptr; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
+  p.rowsub = nullptr; p.emul = nullptr; p.sRow = 0; p.rowmul = nullptr; p.rowout = nullptr; p.flag = nullptr; p.pred = pred;
+  p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
+  const bool a_kc = !transA, b_kc = transB != 0;
+  ODVAE_CHECK_ARG((a_kc ? (int64_t)BM * lda : (int64_t)p.k_per_split * lda) * 4 < 0x7FFFFFF0ll &&
+                  (b_kc ? (int64_t)BN * ldb : (int64_t)p.k_per_split * ldb) * 4 < 0x7FFFFFF0ll, "gemm_pred: one block's operand window exceeds 2 GiB");
+  const int tiles = p.tiles_m * ceil_div(N, BN);
+  const dim3 grid((unsigned)std::min<int64_t>((int64_t)tiles * batch, 1024)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a_kc && b_kc)       hipLaunchKernelGGL((gemm_f32_pred_kernel<true, true>), grid, block, 0, st, p, tiles, batch);
+  else if (a_kc)          hipLaunchKernelGGL((gemm_f32_pred_kernel<true, false>), grid, block, 0, st, p, tiles, batch);
+  else if (b_kc)          hipLaunchKernelGGL((gemm_f32_pred_kernel<false, true>), grid, block, 0, st, p, tiles, batch);
+  else                    hipLaunchKernelGGL((gemm_f32_pred_kernel<false, false>), grid, block, 0, st, p, tiles, batch);
+  ODVAE_LAUNCH_CHECK("gemm_pred");
+  return ODVAE_OK;
+}
+
+static int gemm_f32_impl(int transA, int transB, int M, int N, int K, float alpha,
+                         const float* A, int lda, int64_t strideA,
+                         const float* B, int ldb, int64_t strideB,
+                         float* C, int ldc, int64_t strideC,
+                         const float* bias, const float* residual, int batch,
+                         void* workspace, size_t workspace_bytes, void* stream) {
   ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_f32: empty shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   ODVAE_CHECK_ARG(A && B && C, "gemm_f32: null operand");
   ODVAE_CHECK_ARG(batch <= 65535, "gemm_f32: batch %d > 65535", batch);
@@ -522,7 +651,7 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.residual = residual; p.partial = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
-  p.rowsub = nullptr; p.emul = nullptr; p.sRow = 0;
+  p.rowsub = nullptr; p.emul = nullptr; p.sRow = 0; p.rowmul = nullptr; p.rowout = nullptr; p.flag = nullptr; p.pred = nullptr;
   p.splits = choose_splits(M, N, K, batch);
   p.k_per_split = ceil_div(ceil_div(K, p.splits), BK) * BK;
   p.tiles_m = ceil_div(M, BM);
@@ -583,11 +712,32 @@ int odvae_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 // A [M][K], B [N][K] (both k-contiguous), P and dS [M][N] with leading dimension ldc and batch stride strideC (dS may
 // alias P), rowdot [batch][M] with batch stride strideRow.  Replaces bmm + the softmax backward of
 // [UPSTREAM] ldm AttnBlock.forward under autograd.
+static int gemm_smb_impl(int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA, const float* B, int ldb, int64_t strideB,
+                         const float* P, const float* rowdot, const float* rowmul, int64_t strideRow,
+                         float* dS, int ldc, int64_t strideC, int batch, void* stream);
+
 int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha,
                                const float* A, int lda, int64_t strideA,
                                const float* B, int ldb, int64_t strideB,
                                const float* P, const float* rowdot, int64_t strideRow,
                                float* dS, int ldc, int64_t strideC, int batch, void* stream) {
+  return gemm_smb_impl(M, N, K, alpha, A, lda, strideA, B, ldb, strideB, P, rowdot, nullptr, strideRow, dS, ldc, strideC, batch, stream);
+}
+
+// The same with the probabilities given as unnormalised exponentials E and 1 / l per row (odvae_attention_fwd_f32's folded softmax):
+//   dS = alpha * E .* rinv[row] .* (A B^T - rowdot[row])
+int odvae_gemm_softmax_bwd_scaled_f32(int M, int N, int K, float alpha,
+                                      const float* A, int lda, int64_t strideA,
+                                      const float* B, int ldb, int64_t strideB,
+                                      const float* E, const float* rowdot, const float* rinv, int64_t strideRow,
+                                      float* dS, int ldc, int64_t strideC, int batch, void* stream) {
+  ODVAE_CHECK_ARG(rinv, "gemm_softmax_bwd_scaled: null row factor");
+  return gemm_smb_impl(M, N, K, alpha, A, lda, strideA, B, ldb, strideB, E, rowdot, rinv, strideRow, dS, ldc, strideC, batch, stream);
+}
+
+static int gemm_smb_impl(int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA, const float* B, int ldb, int64_t strideB,
+                         const float* P, const float* rowdot, const float* rowmul, int64_t strideRow,
+                         float* dS, int ldc, int64_t strideC, int batch, void* stream) {
   ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0, "gemm_softmax_bwd: empty shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
   ODVAE_CHECK_ARG(A && B && P && rowdot && dS, "gemm_softmax_bwd: null operand");
   ODVAE_CHECK_ARG(batch <= 65535, "gemm_softmax_bwd: batch %d > 65535", batch);
@@ -600,7 +750,7 @@ int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha,
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
   p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
-  p.rowsub = rowdot; p.emul = P; p.sRow = strideRow;
+  p.rowsub = rowdot; p.emul = P; p.sRow = strideRow; p.rowmul = rowmul; p.rowout = nullptr; p.flag = nullptr; p.pred = nullptr;
   dim3 grid(p.tiles_m * ceil_div(N, BN), 1, batch), block(256);
   if (dma_mode() == 2) {
     const int rc = launch_dma(gemm_f32_dma_kernel<true, true, true, 16>, grid, static_cast<hipStream_t>(stream), p, DmaGeom<16>::LDS_B);
@@ -612,6 +762,51 @@ int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha,
     hipLaunchKernelGGL((gemm_f32_kernel<true, true, true>), grid, block, 0, static_cast<hipStream_t>(stream), p);
   }
   ODVAE_LAUNCH_CHECK("gemm_softmax_bwd");
+  return ODVAE_OK;
+}
+
+// Attention forward with the softmax folded into the two products ([UPSTREAM] AttnBlock.forward: bmm -> softmax -> bmm).
+// (1) E = exp(alpha * (A B^T - rowbound[row])): A [M][K], B [N][K] k-contiguous; rowbound[i] >= max_j (A B^T)[i][j] (odvae_attn_row_bound_f32)
+int odvae_gemm_exp_bound_f32(int M, int N, int K, float alpha,
+                             const float* A, int lda, int64_t strideA, const float* B, int ldb, int64_t strideB,
+                             const float* rowbound, int64_t strideRow, float* E, int ldc, int64_t strideC, int batch, void* stream) {
+  ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "gemm_exp_bound: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  ODVAE_CHECK_ARG(A && B && rowbound && E, "gemm_exp_bound: null operand");
+  ODVAE_CHECK_ARG((int64_t)BM * ldc * 4 < 0x7FFFFFF0ll, "gemm_exp_bound: ldc %d too large for 32-bit tile offsets", ldc);
+  ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 && K % 4 == 0,
+                  "gemm_exp_bound: lda/ldb/strides/K must be multiples of 4 floats");
+  ODVAE_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_exp_bound: A/B must be 16-byte aligned");
+  GemmParams p;
+  p.A = A; p.B = B; p.C = E; p.bias = nullptr; p.residual = nullptr; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = alpha;
+  p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
+  p.rowsub = rowbound; p.emul = nullptr; p.sRow = strideRow; p.rowmul = nullptr; p.rowout = nullptr; p.flag = nullptr; p.pred = nullptr;
+  hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_EXPB>), dim3(p.tiles_m * ceil_div(N, BN), 1, batch), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  ODVAE_LAUNCH_CHECK("gemm_exp_bound");
+  return ODVAE_OK;
+}
+
+// (2) C = (A B) / l[row], l[row] = sum_k A[row][k]: A [M][K] k-contiguous (the exponentials), B [K][N] n-contiguous (V);
+//     rinv[batch][M] = 1 / l; *flag |= 1 if some l is not a normal number >= 1e-30 (the bound was too loose: every exponential of a
+//     row underflowed -- the caller's predicated fallback then redoes the block with the row maximum)
+int odvae_gemm_rownorm_f32(int M, int N, int K, const float* A, int lda, int64_t strideA, const float* B, int ldb, int64_t strideB,
+                           float* C, int ldc, int64_t strideC, float* rinv, int64_t strideRow, int* flag, int batch, void* stream) {
+  ODVAE_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "gemm_rownorm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  ODVAE_CHECK_ARG(A && B && C && rinv, "gemm_rownorm: null operand");
+  ODVAE_CHECK_ARG((int64_t)BM * ldc * 4 < 0x7FFFFFF0ll && (int64_t)BM * lda * 4 < 0x7FFFFFF0ll && (int64_t)K * ldb * 4 < 0x7FFFFFF0ll,
+                  "gemm_rownorm: operand window too large for 32-bit offsets");
+  ODVAE_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 && K % 4 == 0 && N % 4 == 0,
+                  "gemm_rownorm: lda/ldb/strides/K/N must be multiples of 4 floats");
+  ODVAE_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_rownorm: A/B must be 16-byte aligned");
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.residual = nullptr; p.partial = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.sA = strideA; p.sB = strideB; p.sC = strideC; p.alpha = 1.f;
+  p.splits = 1; p.k_per_split = ceil_div(K, BK) * BK; p.tiles_m = ceil_div(M, BM);
+  p.rowsub = nullptr; p.emul = nullptr; p.sRow = strideRow; p.rowmul = nullptr; p.rowout = rinv; p.flag = flag; p.pred = nullptr;
+  hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_ROWNORM>), dim3(p.tiles_m * ceil_div(N, BN), 1, batch), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  ODVAE_LAUNCH_CHECK("gemm_rownorm");
   return ODVAE_OK;
 }
 

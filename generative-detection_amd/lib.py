@@ -25,6 +25,13 @@ PROTOTYPES = {
     "odvae_gemm_f32": (_I, [_I, _I, _I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _P, _I, _P, _Z, _P]),
     "odvae_gemm_softmax_bwd_f32": (_I, [_I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _P, _L, _P, _I, _L, _I, _P]),
     "odvae_rowdot_f32": (_I, [_P, _P, _L, _I, _P, _P]),
+    "odvae_attn_row_bound_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "odvae_gemm_exp_bound_f32": (_I, [_I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _L, _P, _I, _L, _I, _P]),
+    "odvae_gemm_rownorm_f32": (_I, [_I, _I, _I, _P, _I, _L, _P, _I, _L, _P, _I, _L, _P, _L, _P, _I, _P]),
+    "odvae_gemm_pred_f32": (_I, [_I, _I, _I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _I, _L, _I, _P, _P]),
+    "odvae_softmax_rows_pred_f32": (_I, [_P, _P, _L, _I, _F, _P, _P, _P]),
+    "odvae_rowdot_scale_f32": (_I, [_P, _P, _P, _L, _I, _P, _P, _P]),
+    "odvae_gemm_softmax_bwd_scaled_f32": (_I, [_I, _I, _I, _F, _P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _P, _I, _L, _I, _P]),
     "odvae_conv3x3_pack_reduce_pad": (_I, [_I]),
     "odvae_conv3x3_pack_out_pad": (_I, [_I]),
     "odvae_conv3x3_pack_floats": (_Z, [_I, _I]),

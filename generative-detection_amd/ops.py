@@ -614,6 +614,15 @@ def conv1x1(x, weight, bias=None, residual=None):
 FUSED_SOFTMAX_BWD = os.environ.get("ODVAE_ATTN_UNFUSED", "0") != "1"
 
 
+# Row softmax folded into the two products of the forward (include/odvae_hip.h, odvae_attn_row_bound_f32 ...): the QK^T epilogue writes
+# E = exp(scale (s - bound_i)) against the Cauchy-Schwarz bound of the row's scores, the PV product sums the rows of E beside its multiplies
+# and normalises its result; the backward takes P = E / l through row factors.  No softmax pass over the T x T tensor.  A bound too loose
+# for f32 (a row whose exponentials all underflow) raises a device flag and predicated fallback launches redo the block with the row
+# maximum.  ODVAE_ATTN_FOLDED_SOFTMAX=0: bmm -> softmax pass -> bmm.
+ATTN_FOLDED_SOFTMAX = os.environ.get("ODVAE_ATTN_FOLDED_SOFTMAX", "1") != "0"
+_ATTN_LAST_FLAG = None
+
+
 class _Attention(Function):
     """Single-head attention over T = H*W tokens from a packed qkv tensor [N, 3C, H, W]:
     softmax(q k^T * C^-0.5) v  ([UPSTREAM] AttnBlock.forward).  Scores live in HBM (T x T per image)."""
@@ -632,16 +641,47 @@ class _Attention(Function):
         k = qkv.as_strided((1,), (1,), qkv.storage_offset() + c)
         v = qkv.as_strided((1,), (1,), qkv.storage_offset() + 2 * c)
         sq = t * c3
-        gemm(0, 1, t, t, c, 1.0, q, c3, sq, k, c3, sq, p, t, t * t, batch=n)
-        _lib.check(L.odvae_softmax_rows_f32(p.data_ptr(), p.data_ptr(), n * t, t, scale, _lib.stream_ptr()), "softmax_rows")
-        gemm(0, 0, t, c, t, 1.0, p, t, t * t, v, c3, sq, o, c, t * c, batch=n)
-        ctx.save_for_backward(qkv, p, o)
+        rinv = None
+        if ATTN_FOLDED_SOFTMAX and L.odvae_gemm_f32_workspace_bytes(t, t, c, n) == 0 and L.odvae_gemm_f32_workspace_bytes(t, c, t, n) == 0:
+            st = _lib.stream_ptr()
+            bound = torch.empty(2, n * t, dtype=torch.float32, device=qkv.device)      # [0]: the bounds, [1]: scratch (|k_j|)
+            rinv = torch.empty(n * t, dtype=torch.float32, device=qkv.device)
+            flag = torch.empty(1, dtype=torch.int32, device=qkv.device)
+            _lib.check(L.odvae_attn_row_bound_f32(q.data_ptr(), n, t, c, bound.data_ptr(), bound[1].data_ptr(), flag.data_ptr(), st), "attn_row_bound")
+            tag = KERNEL_EVENTS.begin(secondary=True)
+            _lib.check(L.odvae_gemm_exp_bound_f32(t, t, c, scale, q.data_ptr(), c3, sq, k.data_ptr(), c3, sq, bound.data_ptr(), t,
+                                                  p.data_ptr(), t, t * t, n, st), "gemm_exp_bound")
+            KERNEL_EVENTS.end("gemm_f32", 2.0 * t * t * c * n, tag, 4.0 * n * (2 * t * c + t * t))
+            tag = KERNEL_EVENTS.begin(secondary=True)
+            _lib.check(L.odvae_gemm_rownorm_f32(t, c, t, p.data_ptr(), t, t * t, v.data_ptr(), c3, sq, o.data_ptr(), c, t * c,
+                                                rinv.data_ptr(), t, flag.data_ptr(), n, st), "gemm_rownorm")
+            KERNEL_EVENTS.end("gemm_f32", 2.0 * t * t * c * n, tag, 4.0 * n * (2 * t * c + t * t))
+            # fallback under the device-side flag (three launches that return at once when it is 0): exact softmax, row factors 1
+            _lib.check(L.odvae_gemm_pred_f32(0, 1, t, t, c, 1.0, q.data_ptr(), c3, sq, k.data_ptr(), c3, sq, p.data_ptr(), t, t * t, n,
+                                             flag.data_ptr(), st), "gemm_pred(QK^T)")
+            _lib.check(L.odvae_softmax_rows_pred_f32(p.data_ptr(), p.data_ptr(), n * t, t, scale, flag.data_ptr(), rinv.data_ptr(), st), "softmax_rows_pred")
+            _lib.check(L.odvae_gemm_pred_f32(0, 0, t, c, t, 1.0, p.data_ptr(), t, t * t, v.data_ptr(), c3, sq, o.data_ptr(), c, t * c, n,
+                                             flag.data_ptr(), st), "gemm_pred(PV)")
+            global _ATTN_LAST_FLAG
+            _ATTN_LAST_FLAG = flag      # (diagnostics / tests: 1 after a forward whose bound underflowed and whose fallback ran)
+        else:
+            gemm(0, 1, t, t, c, 1.0, q, c3, sq, k, c3, sq, p, t, t * t, batch=n)
+            _lib.check(L.odvae_softmax_rows_f32(p.data_ptr(), p.data_ptr(), n * t, t, scale, _lib.stream_ptr()), "softmax_rows")
+            gemm(0, 0, t, c, t, 1.0, p, t, t * t, v, c3, sq, o, c, t * c, batch=n)
+        ctx.folded = rinv is not None
+        if rinv is not None:
+            ctx.save_for_backward(qkv, p, o, rinv)
+        else:
+            ctx.save_for_backward(qkv, p, o)
         return o
 
     @staticmethod
     def backward(ctx, do):
         L = _L()
-        qkv, p, o = ctx.saved_tensors
+        if ctx.folded:
+            qkv, p, o, rinv = ctx.saved_tensors      # p holds E = exp(scale (s - bound)), P = E * rinv[row]
+        else:
+            (qkv, p, o), rinv = ctx.saved_tensors, None
         do = _cl(do)
         n, c3, h, w = qkv.shape
         c = c3 // 3
@@ -655,6 +695,23 @@ class _Attention(Function):
         dq = dqkv.as_strided((1,), (1,), dqkv.storage_offset())
         dk = dqkv.as_strided((1,), (1,), dqkv.storage_offset() + c)
         dv = dqkv.as_strided((1,), (1,), dqkv.storage_offset() + 2 * c)
+        if rinv is not None:
+            # D_i = dO_i . O_i and dO_i / l_i in one pass over dO; dV = E^T (dO / l); dS = scale E rinv (dO V^T - D)
+            drow = torch.empty(n * t, dtype=torch.float32, device=p.device)
+            dos = torch.empty_like(do)
+            _lib.check(L.odvae_rowdot_scale_f32(do.data_ptr(), o.data_ptr(), rinv.data_ptr(), n * t, c, drow.data_ptr(), dos.data_ptr(),
+                                                _lib.stream_ptr()), "rowdot_scale")
+            gemm(1, 0, t, c, t, 1.0, p, t, t * t, dos, c, t * c, dv, c3, sq, batch=n)
+            del dos
+            dp = torch.empty_like(p)
+            tag = KERNEL_EVENTS.begin(secondary=True)
+            _lib.check(L.odvae_gemm_softmax_bwd_scaled_f32(t, t, c, scale, do.data_ptr(), c, t * c, v.data_ptr(), c3, sq, p.data_ptr(),
+                                                           drow.data_ptr(), rinv.data_ptr(), t, dp.data_ptr(), t, t * t, n, _lib.stream_ptr()),
+                       "gemm_softmax_bwd_scaled")
+            KERNEL_EVENTS.end("gemm_f32", 2.0 * t * t * c * n, tag, 4.0 * n * (2 * t * c + 2 * t * t))
+            gemm(0, 0, t, c, t, 1.0, dp, t, t * t, k, c3, sq, dq, c3, sq, batch=n)
+            gemm(1, 0, t, c, t, 1.0, dp, t, t * t, q, c3, sq, dk, c3, sq, batch=n)
+            return dqkv
         # dV = P^T dO
         gemm(1, 0, t, c, t, 1.0, p, t, t * t, do, c, t * c, dv, c3, sq, batch=n)
         # dS = scale * P .* (dO V^T - D), D[i] = sum_j P[i][j] dP[i][j] = dO[i] . O[i]: the softmax backward rides in the

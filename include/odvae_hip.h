@@ -194,6 +194,32 @@ int odvae_rowdot_f32(const float* a, const float* b, int64_t rows, int cols, flo
 int odvae_gemm_softmax_bwd_f32(int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA,
                                const float* B, int ldb, int64_t strideB, const float* P, const float* rowdot,
                                int64_t strideRow, float* dS, int ldc, int64_t strideC, int batch, void* stream);
+/* Attention forward with the row softmax folded into the two products ([UPSTREAM] ldm AttnBlock.forward: bmm -> softmax(dim=2) -> bmm).
+ * softmax is invariant to the shift it subtracts, so the QK^T epilogue can write E = exp(scale * (q_i . k_j - bound_i)) against any bound_i >=
+ * max_j q_i . k_j -- |q_i| * max_j |k_j| -- instead of waiting for the row maximum, and the PV product sums l_i = sum_j E_ij beside its
+ * multiplies and divides by it: P = E / l is never formed, the T x T tensor is written once and read once (the separate softmax pass read and
+ * rewrote it: 3.9 of 232 ms per step).  A bound far above the maximum underflows a whole row; odvae_gemm_rownorm_f32 then raises *flag and
+ * the caller's PREDICATED fallback launches (odvae_gemm_pred_f32, odvae_softmax_rows_pred_f32: no-ops unless *flag != 0) redo the block with
+ * the row maximum -- no host synchronisation either way.
+ *   odvae_attn_row_bound_f32: qkv [N][T][3C] (q | k | v per token) -> bound [N*T] (unscaled), *flag = 0; nk_scratch [N*T]
+ *   odvae_gemm_exp_bound_f32: E = exp(alpha * (A B^T - rowbound[row])); A [M][K], B [N][K]
+ *   odvae_gemm_rownorm_f32:   C = (A B) / l[row], l = row sums of A [M][K]; B [K][N]; rinv [batch][M] = 1 / l; *flag |= (some l < 1e-30 or not finite)
+ *   odvae_gemm_pred_f32:      odvae_gemm_f32 (unsplit shapes, no bias / residual) under the predicate
+ *   odvae_softmax_rows_pred_f32: odvae_softmax_rows_f32 under the predicate, and ones[row] = 1
+ * Backward with P given as (E, rinv): odvae_rowdot_scale_f32 (out[i] = a_i . b_i, a_scaled[i][:] = a[i][:] * row_scale[i]: D_i and dO_i / l_i),
+ * odvae_gemm_softmax_bwd_scaled_f32 (dS = alpha * E .* rinv[row] .* (A B^T - rowdot[row])). */
+int odvae_attn_row_bound_f32(const float* qkv, int N, int T, int C, float* bound, float* nk_scratch, int* flag, void* stream);
+int odvae_gemm_exp_bound_f32(int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA, const float* B, int ldb, int64_t strideB,
+                             const float* rowbound, int64_t strideRow, float* E, int ldc, int64_t strideC, int batch, void* stream);
+int odvae_gemm_rownorm_f32(int M, int N, int K, const float* A, int lda, int64_t strideA, const float* B, int ldb, int64_t strideB,
+                           float* C, int ldc, int64_t strideC, float* rinv, int64_t strideRow, int* flag, int batch, void* stream);
+int odvae_gemm_pred_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA,
+                        const float* B, int ldb, int64_t strideB, float* C, int ldc, int64_t strideC, int batch, const int* pred, void* stream);
+int odvae_softmax_rows_pred_f32(const float* x, float* y, int64_t rows, int cols, float scale, const int* pred, float* ones, void* stream);
+int odvae_rowdot_scale_f32(const float* a, const float* b, const float* row_scale, int64_t rows, int cols, float* out, float* a_scaled, void* stream);
+int odvae_gemm_softmax_bwd_scaled_f32(int M, int N, int K, float alpha, const float* A, int lda, int64_t strideA,
+                                      const float* B, int ldb, int64_t strideB, const float* E, const float* rowdot, const float* rinv,
+                                      int64_t strideRow, float* dS, int ldc, int64_t strideC, int batch, void* stream);
 /* backward of F.interpolate(scale_factor=2, mode="nearest"): dx[N][H][W][C] from du[N][2H][2W][C] */
 int odvae_upsample2x_bwd_f32(const float* du, float* dx, int N, int H, int W, int C, void* stream);
 /* PoseAutoencoder._rescale (src/models/autoencoder.py:434-436): NCHW in, NHWC out; workspace >= 8 KiB */

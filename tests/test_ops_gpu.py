@@ -540,11 +540,51 @@ def test_attention(hip_lib, gemm_staging, monkeypatch, n, c, h, w, fused):
     o_ref = torch.bmm(v.reshape(n, c, t), w_.permute(0, 2, 1)).reshape(n, c, h, w)
     go = torch.randn(o_ref.shape, generator=g)
     o_ref.backward(go)
-    qd = qkv.to(dev()).requires_grad_(True)
-    o = ops.attention_qkv(qd)
-    close(o, o_ref, FWD_TOL, "attn fwd")
-    o.backward(go.to(dev()))
-    close(qd.grad, qr.grad, BWD_TOL, "attn dqkv")
+    outs = {}
+    for folded in (True, False):      # folded: softmax inside the two forward products (exp against a row bound, row sums in the PV product)
+        monkeypatch.setattr(ops, "ATTN_FOLDED_SOFTMAX", folded)
+        qd = qkv.to(dev()).requires_grad_(True)
+        o = ops.attention_qkv(qd)
+        close(o, o_ref, FWD_TOL, "attn fwd (folded softmax: %s)" % folded)
+        o.backward(go.to(dev()))
+        close(qd.grad, qr.grad, BWD_TOL, "attn dqkv (folded softmax: %s)" % folded)
+        if folded:
+            assert int(ops._ATTN_LAST_FLAG.item()) == 0      # the bound held: no fallback ran
+        outs[folded] = (o.detach(), qd.grad)
+    for a, b, what in zip(outs[True], outs[False], ("o", "dqkv")):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), what + ": folded vs separate softmax"   # (exp arguments are ~|bound| instead of ~|max| below zero: their f32 rounding scales with it)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 16, 16), (1, 128, 10, 18)])
+def test_attention_folded_softmax_falls_back_when_the_row_bound_underflows(hip_lib, monkeypatch, n, c, h, w):
+    """|q_i| max_j |k_j| C^-1/2 far above the largest score of the row (long q and k at right angles): every exponential relative to
+    the bound is 0 in f32, the PV product sees a zero row sum and raises the device flag, and the predicated fallback launches redo the
+    block with the row maximum -- same result as the separate softmax pass, forward and backward, without a host round trip."""
+    from odvae_amd import ops
+    g = torch.Generator().manual_seed(c + h)
+    qkv = torch.randn(n, 3 * c, h, w, generator=g)
+    qkv[:, 0] += 400.0            # q: a large component along channel 0
+    qkv[:, c + 1] += 400.0        # k: a large component along channel 1  ->  bound ~ 1.6e5 / sqrt(c), scores O(100)
+    t = h * w
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr[:, :c], qr[:, c:2 * c], qr[:, 2 * c:]
+    w_ = F.softmax(torch.bmm(q.reshape(n, c, t).permute(0, 2, 1), k.reshape(n, c, t)) * (c ** -0.5), dim=2)
+    o_ref = torch.bmm(v.reshape(n, c, t), w_.permute(0, 2, 1)).reshape(n, c, h, w)
+    go = torch.randn(o_ref.shape, generator=g)
+    o_ref.backward(go)
+    outs = {}
+    for folded in (True, False):
+        monkeypatch.setattr(ops, "ATTN_FOLDED_SOFTMAX", folded)
+        qd = qkv.to(dev()).requires_grad_(True)
+        o = ops.attention_qkv(qd)
+        if folded:
+            assert int(ops._ATTN_LAST_FLAG.item()) == 1      # the fallback did run
+        o.backward(go.to(dev()))
+        outs[folded] = (o.detach(), qd.grad)
+    assert torch.equal(outs[True][0], outs[False][0])         # the fallback IS the separate-pass computation
+    close(outs[True][0], o_ref, FWD_TOL, "attn fwd after the fallback")
+    close(outs[True][1], outs[False][1], 1e-6, "attn dqkv after the fallback vs the separate pass")
+    close(outs[True][1], qr.grad, BWD_TOL * 4, "attn dqkv after the fallback")
 
 
 @pytest.mark.parametrize("n,c,h,w,budget_images", [(5, 64, 16, 16, 2), (3, 32, 10, 18, 1), (6, 256, 8, 16, 4)])
@@ -569,7 +609,8 @@ def test_attention_with_score_budget(hip_lib, monkeypatch, n, c, h, w, budget_im
     close(o, o_ref, FWD_TOL, "attn fwd (score budget)")
     o.backward(go.to(dev()))
     close(qd.grad, qr.grad, BWD_TOL, "attn dqkv (score budget)")
-    # same numbers as the all-resident path (same kernels, same order inside a group)
+    # same numbers as the all-resident path with its softmax as a separate pass (same kernels, same order inside a group)
+    monkeypatch.setattr(ops, "ATTN_FOLDED_SOFTMAX", False)
     monkeypatch.setattr(ops, "ATTN_SCORE_BUDGET", 1 << 40)
     q2 = qkv.to(dev()).requires_grad_(True)
     o2 = ops.attention_qkv(q2)
