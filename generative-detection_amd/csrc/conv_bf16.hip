@@ -113,22 +113,35 @@ __global__ __launch_bounds__(256, MINW) void conv_bf16_kernel(ConvB p) {
     const int64_t img = (int64_t)n * p.Ho * p.Wo * p.Cout;
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.residual ? p.residual + img : p.x), 0, p.residual ? p.Ho * p.Wo * p.Cout * 2 : 0, 0x00020000);
+    // No guards: bias and residual come through buffer descriptors that are EMPTY when the operand is absent and end at its last element
+    // otherwise (out-of-range dwords read 0).  With `p.bias ? p.bias[co] : 0` / `if (p.residual)` hipcc built 32 exec-masked loads and 16
+    // residual loads each behind its own branch and each waited for with vmcnt(0) -- a chain of ~48 memory round trips in front of the
+    // first MFMA of every block; now all of them are in flight together.
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias : reinterpret_cast<const float*>(p.x)), 0, p.bias ? p.Cout * 4 : 0, 0x00020000);
+    u32x4 bq[WCT][4];
+    u32x2 rq[WCT][4][WPT];
 #pragma unroll
     for (int ct = 0; ct < WCT; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int co = co0 + (wco * WCT + ct) * 32 + 8 * g + 4 * h;
-        float bv[4];
+        bq[ct][g] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, (unsigned)co * 4u, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
+        for (int pt = 0; pt < WPT; ++pt) {   // Cout % 4 == 0 is checked on the host when a residual is given
+          const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
+          rq[ct][g][pt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
+        }
+      }
+#pragma unroll
+    for (int ct = 0; ct < WCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float bv[4] = {__uint_as_float(bq[ct][g].x), __uint_as_float(bq[ct][g].y), __uint_as_float(bq[ct][g].z), __uint_as_float(bq[ct][g].w)};
 #pragma unroll
         for (int pt = 0; pt < WPT; ++pt) {
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.residual) {   // Cout % 4 == 0 is checked on the host when a residual is given
-            const unsigned off = (pixoff[pt] != OOB && co < p.Cout) ? (pixoff[pt] + (unsigned)co) * 2u : OOB;
-            const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rrsrc, off, 0, 0));
-            rv[0] = bf16_lo(v.x); rv[1] = bf16_hi(v.x); rv[2] = bf16_lo(v.y); rv[3] = bf16_hi(v.y);
-          }
+          const u32x2 v = rq[ct][g][pt];
+          const float rv[4] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y)};
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[ct][pt][4 * g + j] = bv[j] + rv[j];
         }
@@ -342,7 +355,11 @@ void launch_by_cout(ConvB& p, hipStream_t st) {
   if constexpr (MODE == 0) {
     if (p.gn_partial) { launch_cfg<MODE, KC, 2, 2, 2, 2, 8, 1, true>(p, dim3(tiles, ceil_div(p.Cout, 128)), st); return; }
   }
-  if (p.Cout > 64)      launch_cfg<MODE, KC, 2, 2, 2, 2, 8>(p, dim3(tiles, ceil_div(p.Cout, 128)), st);
+  // (three blocks per CU where the kernel fits 168 registers without spilling: the stride-2, transposed and 1x1 forms, 76.2 -> 75.3 ms per
+  // bf16 step.  The stride-1 3x3 form needs 176: with the hint it parks the next chunk's halo registers in scratch, 86.5 ms; in 32-channel
+  // chunks it fits (162-167 registers, three blocks) and runs exactly as fast as 64-channel chunks at two blocks, 75.3-75.5 ms either way)
+  constexpr int MW = (MODE == 2 || MODE == 3 || MODE == 4) ? 3 : 1;
+  if (p.Cout > 64)      launch_cfg<MODE, KC, 2, 2, 2, 2, 8, MW>(p, dim3(tiles, ceil_div(p.Cout, 128)), st);
   else if (p.Cout > 32) launch_cfg<MODE, KC, 2, 1, 1, 4, 8>(p, dim3(tiles, 1), st);
   else                  launch_cfg<MODE, KC, 1, 1, 1, 4, 8>(p, dim3(tiles, 1), st);
 }
