@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "odvae_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 2   # == ODVAE_ABI_VERSION in include/odvae_hip.h; bumped whenever the exported surface changes
+ABI_VERSION = 3   # == ODVAE_ABI_VERSION in include/odvae_hip.h; bumped whenever the exported surface changes
 
 # name -> (restype, argtypes); mirrors include/odvae_hip.h one to one (tests/test_abi.py checks that)
 PROTOTYPES = {

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ODVAE_ABI_VERSION 2            /* odvae_abi_version() of a library built from this header */
+#define ODVAE_ABI_VERSION 3            /* odvae_abi_version() of a library built from this header */
 #define ODVAE_OK 0
 #define ODVAE_ERR_ARG 1
 #define ODVAE_ERR_WORKSPACE 2
