@@ -576,6 +576,16 @@ def main():
                                         "algorithmic_tflops is the direct-convolution work (2*9*Cin*Cout per pixel, SURVEY.md 8(d)) "
                                         "the same launches deliver" + (", 4x the issued work under Winograd F(4x4,3x3)" if wino4 else
                                                                        ", 36/16 of the issued work under Winograd" if wino else ""))}
+            if wino4:
+                # the family is one kernel template with different epilogues (rocprof lists them as conv3x3_wino4_kernel<EPI, UP>): the
+                # aggregate above prices ALL of them on their matrix work, including the launches whose output transform also carries the
+                # GroupNorm statistics / the first pass of a GroupNorm backward (x read once more, ~14 vector operations per element)
+                out["roofline"]["variants"] = []
+                for v in ops.KERNEL_EVENTS.variants("conv3x3_wino4"):
+                    rv = ops.KERNEL_EVENTS.summary("conv3x3_wino4|" + v)
+                    out["roofline"]["variants"].append({"epilogue": v, "launches": rv["launches"], "avg_launch_ms": rv["avg_ms"],
+                                                        "achieved": rv["issued_tflops"], "frac": rv["issued_tflops"] / mfma_peak,
+                                                        "total_ms_per_step": rv["total_ms"] / args.steps})
             # whole step: every multiply-add issued by the MFMA kernels of the timed steps (host-side count per launch)
             step_issued = ops.KERNEL_EVENTS.issued_timed / args.steps
             out["roofline_step"] = {"bound": "mfma", "issued_tflop_per_step": step_issued / 1e12,
@@ -635,6 +645,10 @@ def main():
             oc["configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder"] = side_run(dev, 512, 32, 4, 2, True, "bf16")
             oc["configs[3] 256x256 B=32 fp32, PatchGAN discriminator + LPIPS-style loss, both optimizers"] = side_run(dev, 256, 32, 4, 2, False, 32, gan=True)
             oc["configs[1] shape in bf16, repeated after the 512x512 and GAN runs"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
+            # the data-parallel path's overhead is the difference between THESE two adjacent runs (the headline ran first, on a cooler chip
+            # and an empty allocator: a side run of the same step after the others has measured up to 1.7 % slower than it)
+            oc["configs[1] (256x256, B=32, fp32) repeated as a side run (single process), for the next line to compare with"] = \
+                side_run(dev, 256, 32, 6, 2, False, 32)
             oc["configs[1] (256x256, B=32, fp32) through the data-parallel path: RCCL world size 1, bucketed reducer"] = \
                 side_run(dev, 256, 32, 6, 2, False, 32, force_dist=True)
             out["other_configs"] = oc

@@ -81,16 +81,24 @@ class _KernelEvents:
         ev.record()
         return ev
 
-    def end(self, name, flops, ev0, nbytes=0.0, issued=None):
+    def end(self, name, flops, ev0, nbytes=0.0, issued=None, variant=None):
         """flops = ALGORITHMIC work of the launch (direct form); issued = multiply-add work actually sent to the MFMA pipe
-        (defaults to flops)."""
+        (defaults to flops).  variant: which instantiation of the family's kernel ran (its epilogue); the same record is then also
+        listed under "name|variant" (summary("name|variant"), variants(name)): the family figure aggregates kernels that do different
+        amounts of non-matrix work per launch."""
         if self.on:
             self.issued += flops if issued is None else issued
         if ev0 is None:
             return
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        self.rec.setdefault(name, []).append((flops, ev0, ev1, nbytes, flops if issued is None else issued))
+        item = (flops, ev0, ev1, nbytes, flops if issued is None else issued)
+        self.rec.setdefault(name, []).append(item)
+        if variant is not None:
+            self.rec.setdefault(name + "|" + variant, []).append(item)
+
+    def variants(self, name):
+        return sorted(k.split("|", 1)[1] for k in self.rec if k.startswith(name + "|"))
 
     def summary(self, name):
         torch.cuda.synchronize()
@@ -384,7 +392,8 @@ def _conv3x3_wino_raw(x, pack, cin, cout, bias, residual, act=0, f4=False, stats
     # issued multiply-adds per output pixel and (ci, co): F(2x2,3x3) 16 per 2x2 tile = 4, F(4x4,3x3) 36 per 4x4 tile = 2.25
     KERNEL_EVENTS.end("conv3x3_wino4" if f4 else "conv3x3_128x128", 2.0 * 9 * cin * cout * n * h * w, tag,
                       4.0 * (n * h * w * cin // (4 if up else 1) + n * h * w * cout * (2 if residual is not None else 1) + 9 * cin * cout),
-                      issued=2.0 * (2.25 if f4 else 4.0) * cin * cout * n * h * w)
+                      issued=2.0 * (2.25 if f4 else 4.0) * cin * cout * n * h * w,
+                      variant=(("upsample" if up else "plain") + (" + GroupNorm statistics" if stats else "")) if f4 else None)
     return (y, partial) if stats else y
 
 
@@ -457,7 +466,7 @@ class _Conv3x3(Function):
                 _lib.check(L.odvae_conv3x3_wino4_pool_f32(dy.data_ptr(), n, ho, wo, cout, dgr.data_ptr(), cin, dx.data_ptr(), _lib.stream_ptr()),
                            "conv3x3_wino4_pool")
                 KERNEL_EVENTS.end("conv3x3_wino4", 2.0 * 9 * cin * cout * n * ho * wo, tag, 4.0 * (n * ho * wo * cout + n * hi * wi * cin + 9 * cin * cout),
-                                  issued=2.0 * 2.25 * cin * cout * n * ho * wo)
+                                  issued=2.0 * 2.25 * cin * cout * n * ho * wo, variant="data gradient, 2x2-summed (Upsample)")
             elif ctx.up == "wino4up":   # the same in two steps: full-resolution gradient, then its 2x2 sum-pool
                 du = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=True)
                 dx = _new_cl(n, cin, hi, wi, x)
@@ -471,8 +480,8 @@ class _Conv3x3(Function):
                 _lib.check(L.odvae_conv3x3_wino4_gnbwd_f32(dy.data_ptr(), n, hi, wi, cout, dgr.data_ptr(), cin, dx.data_ptr(), lk.x.data_ptr(),
                                                            lk.mean.data_ptr(), lk.rstd.data_ptr(), lk.gamma.data_ptr(), lk.beta.data_ptr(),
                                                            lk.groups, sums.data_ptr(), _lib.stream_ptr()), "conv3x3_wino4_gnbwd")
-                KERNEL_EVENTS.end("conv3x3_wino4", 2.0 * 9 * cin * cout * n * hi * wi, tag, 4.0 * (n * hi * wi * (cin + cout) + 9 * cin * cout),
-                                  issued=2.0 * 2.25 * cin * cout * n * hi * wi)
+                KERNEL_EVENTS.end("conv3x3_wino4", 2.0 * 9 * cin * cout * n * hi * wi, tag, 4.0 * (n * hi * wi * (2 * cin + cout) + 9 * cin * cout),
+                                  issued=2.0 * 2.25 * cin * cout * n * hi * wi, variant="data gradient + GroupNorm-backward sums")
                 lk.sums = (sums, dx.data_ptr(), dx._version, tuple(dx.shape))
             elif ctx.up in ("wino", "wino4"):
                 dx = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=ctx.up == "wino4")
