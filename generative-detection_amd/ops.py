@@ -438,12 +438,15 @@ class _Conv3x3(Function):
         if gn_stats:
             if partial is not None:
                 ctx.mark_non_differentiable(partial)
+            ctx.set_materialize_grads(False)   # the statistics output has no gradient: not a tensor of zeros per backward (a fill launch each)
             return y, partial
         return y
 
     @staticmethod
     def backward(ctx, dy, _dpartial=None):
         L = _L()
+        if dy is None:
+            return None, None, None, None, None, None, None, None
         x, weight, y_act = ctx.saved_tensors
         mode = ctx.mode
         dy = _cl(dy)
@@ -1446,12 +1449,15 @@ class _ConvB(Function):
         if gn_stats:
             if partial is not None:
                 ctx.mark_non_differentiable(partial)
+            ctx.set_materialize_grads(False)   # (as _Conv3x3: no tensor of zeros for the statistics output)
             return y, partial
         return y
 
     @staticmethod
     def backward(ctx, dy, _dpartial=None):
         L = _L()
+        if dy is None:
+            return None, None, None, None, None, None, None
         (x,) = ctx.saved_tensors
         mode = ctx.mode
         cout, cin = ctx.wshape[0], ctx.wshape[1]
