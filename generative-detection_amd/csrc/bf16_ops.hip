@@ -91,6 +91,12 @@ __device__ __forceinline__ void load_oct(const GnB& s, int n, int q, const float
 }
 
 // grid (blocks, N); a thread keeps one channel octet (256 % octs == 0), so the affine constants are loop-invariant registers
+// streaming accesses (`nt`): every byte of these passes is touched once here and next by another kernel a gigabyte later; measured on the
+// f32 twins -4 % (backward apply) / -6 % (forward apply) per launch
+typedef unsigned int gnb_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ldnt(const u32x4* p) { return __builtin_nontemporal_load(reinterpret_cast<const gnb_u4*>(p)); }
+__device__ __forceinline__ void stnt(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<gnb_u4*>(p)); }
+
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const bf16_t* __restrict__ x, GnB s, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, int swish, bf16_t* __restrict__ y) {
@@ -112,10 +118,10 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const bf16_t* __restrict
   };
   int i = blockIdx.x * 256 + threadIdx.x;
   for (; i + 3 * stride < per_n; i += 4 * stride) {
-    const u32x4 v0 = xn[i], v1 = xn[i + stride], v2 = xn[i + 2 * stride], v3 = xn[i + 3 * stride];
-    yn[i] = f(v0); yn[i + stride] = f(v1); yn[i + 2 * stride] = f(v2); yn[i + 3 * stride] = f(v3);
+    const u32x4 v0 = ldnt(xn + i), v1 = ldnt(xn + i + stride), v2 = ldnt(xn + i + 2 * stride), v3 = ldnt(xn + i + 3 * stride);
+    stnt(yn + i, f(v0)); stnt(yn + i + stride, f(v1)); stnt(yn + i + 2 * stride, f(v2)); stnt(yn + i + 3 * stride, f(v3));
   }
-  for (; i < per_n; i += stride) yn[i] = f(xn[i]);
+  for (; i < per_n; i += stride) stnt(yn + i, f(ldnt(xn + i)));
 }
 
 // partial [N][chunks][2][C]: per channel sums of du*xhat and du over the chunk's pixels
@@ -144,10 +150,10 @@ __global__ __launch_bounds__(256) void gnb_bwd_reduce_kernel(const bf16_t* __res
     };
     int px = p_beg + psub;
     for (; px + s.pix_per_pass < p_end; px += 2 * s.pix_per_pass) {         // four 16-byte loads in flight per thread
-      const u32x4 x0 = *reinterpret_cast<const u32x4*>(x + base + (int64_t)px * s.C);
-      const u32x4 d0 = *reinterpret_cast<const u32x4*>(dy + base + (int64_t)px * s.C);
-      const u32x4 x1 = *reinterpret_cast<const u32x4*>(x + base + (int64_t)(px + s.pix_per_pass) * s.C);
-      const u32x4 d1 = *reinterpret_cast<const u32x4*>(dy + base + (int64_t)(px + s.pix_per_pass) * s.C);
+      const u32x4 x0 = ldnt(reinterpret_cast<const u32x4*>(x + base + (int64_t)px * s.C));
+      const u32x4 d0 = ldnt(reinterpret_cast<const u32x4*>(dy + base + (int64_t)px * s.C));
+      const u32x4 x1 = ldnt(reinterpret_cast<const u32x4*>(x + base + (int64_t)(px + s.pix_per_pass) * s.C));
+      const u32x4 d1 = ldnt(reinterpret_cast<const u32x4*>(dy + base + (int64_t)(px + s.pix_per_pass) * s.C));
       accum(x0, d0);
       accum(x1, d1);
     }
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void gnb_bwd_apply_kernel(const bf16_t* __rest
   auto f = [&](const u32x4 xv, const u32x4 dv, int at) {
     float xi[8], di[8], ad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unpack8(xv, xi); unpack8(dv, di);
-    if (an) unpack8(an[at], ad);
+    if (an) unpack8(ldnt(an + at), ad);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xh = (xi[j] - k.mu[j]) * k.rs[j];
@@ -194,10 +200,10 @@ __global__ __launch_bounds__(256) void gnb_bwd_apply_kernel(const bf16_t* __rest
   };
   int i = blockIdx.x * 256 + threadIdx.x;
   for (; i + stride < per_n; i += 2 * stride) {
-    const u32x4 x0 = xn[i], x1 = xn[i + stride], d0 = dn[i], d1 = dn[i + stride];
-    on[i] = f(x0, d0, i); on[i + stride] = f(x1, d1, i + stride);
+    const u32x4 x0 = ldnt(xn + i), x1 = ldnt(xn + i + stride), d0 = ldnt(dn + i), d1 = ldnt(dn + i + stride);
+    stnt(on + i, f(x0, d0, i)); stnt(on + i + stride, f(x1, d1, i + stride));
   }
-  for (; i < per_n; i += stride) on[i] = f(xn[i], dn[i], i);
+  for (; i < per_n; i += stride) stnt(on + i, f(ldnt(xn + i), ldnt(dn + i), i));
 }
 
 bool make_shape(int N, int HW, int C, int G, GnB& s) {

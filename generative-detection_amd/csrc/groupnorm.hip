@@ -28,6 +28,27 @@ struct GnShape {
 __device__ __forceinline__ float sigmoid_f(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-u)); }
 __device__ __forceinline__ float swish_f(float u) { return u * sigmoid_f(u); }
 
+// streaming accesses of the apply passes: every byte is touched once by this kernel and next by another one a gigabyte later
+#ifndef ODVAE_GN_NT
+#define ODVAE_GN_NT 1
+#endif
+typedef float gn_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if ODVAE_GN_NT
+  const gn_f4 v = __builtin_nontemporal_load(reinterpret_cast<const gn_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if ODVAE_GN_NT
+  __builtin_nontemporal_store(gn_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<gn_f4*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // ---- forward statistics -------------------------------------------------------------------------
 // partial: [N][chunks][G][2]  (sum, sum of squares)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, GnShape s, float* __restrict__ partial) {
@@ -118,11 +139,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   if (256 % s.quads == 0) {
     gn_load_quad(s, n, threadIdx.x % s.quads, gamma, beta, mean, rstd, nullptr, k);
     for (; i + 3 * stride < per_n; i += 4 * stride) {
-      const float4 v0 = xn[i], v1 = xn[i + stride], v2 = xn[i + 2 * stride], v3 = xn[i + 3 * stride];
-      yn[i] = gn_apply_quad<SWISH>(v0, k); yn[i + stride] = gn_apply_quad<SWISH>(v1, k);
-      yn[i + 2 * stride] = gn_apply_quad<SWISH>(v2, k); yn[i + 3 * stride] = gn_apply_quad<SWISH>(v3, k);
+      const float4 v0 = ld_stream(xn + i), v1 = ld_stream(xn + i + stride), v2 = ld_stream(xn + i + 2 * stride), v3 = ld_stream(xn + i + 3 * stride);
+      st_stream(yn + i, gn_apply_quad<SWISH>(v0, k)); st_stream(yn + i + stride, gn_apply_quad<SWISH>(v1, k));
+      st_stream(yn + i + 2 * stride, gn_apply_quad<SWISH>(v2, k)); st_stream(yn + i + 3 * stride, gn_apply_quad<SWISH>(v3, k));
     }
-    for (; i < per_n; i += stride) yn[i] = gn_apply_quad<SWISH>(xn[i], k);
+    for (; i < per_n; i += stride) st_stream(yn + i, gn_apply_quad<SWISH>(ld_stream(xn + i), k));
   } else {
     for (; i < per_n; i += stride) {
       gn_load_quad(s, n, i % s.quads, gamma, beta, mean, rstd, nullptr, k);
@@ -163,8 +184,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) { const int g = (c + j) / s.cpg; mu[j] = mean[n * s.G + g]; rs[j] = rstd[n * s.G + g]; }
     const int64_t base = (int64_t)n * s.HW * s.C + c;
     for (int px = p_beg + psub; px < p_end; px += s.pix_per_pass) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + base + (int64_t)px * s.C);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + base + (int64_t)px * s.C);
+      const float4 xv = ld_stream(reinterpret_cast<const float4*>(x + base + (int64_t)px * s.C));
+      const float4 dv = ld_stream(reinterpret_cast<const float4*>(dy + base + (int64_t)px * s.C));
       const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const float4* dn = reinterpret_cast<const float4*>(dy) + (int64_t)n * per_n;
   const float4* an = dx_add ? reinterpret_cast<const float4*>(dx_add) + (int64_t)n * per_n : nullptr;
   auto plus = [&](float4 v, int at) {
-    if (an) { const float4 a = an[at]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    if (an) { const float4 a = ld_stream(an + at); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
     return v;
   };
   float4* on = reinterpret_cast<float4*>(dx) + (int64_t)n * per_n;
@@ -222,10 +243,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   if (256 % s.quads == 0) {
     gn_load_quad(s, n, threadIdx.x % s.quads, gamma, beta, mean, rstd, grp, k);
     for (; i + stride < per_n; i += 2 * stride) {
-      const float4 x0 = xn[i], x1 = xn[i + stride], d0 = dn[i], d1 = dn[i + stride];
-      on[i] = plus(gn_bwd_quad<SWISH>(x0, d0, k, inv_m), i); on[i + stride] = plus(gn_bwd_quad<SWISH>(x1, d1, k, inv_m), i + stride);
+      const float4 x0 = ld_stream(xn + i), x1 = ld_stream(xn + i + stride), d0 = ld_stream(dn + i), d1 = ld_stream(dn + i + stride);
+      st_stream(on + i, plus(gn_bwd_quad<SWISH>(x0, d0, k, inv_m), i)); st_stream(on + i + stride, plus(gn_bwd_quad<SWISH>(x1, d1, k, inv_m), i + stride));
     }
-    for (; i < per_n; i += stride) on[i] = plus(gn_bwd_quad<SWISH>(xn[i], dn[i], k, inv_m), i);
+    for (; i < per_n; i += stride) st_stream(on + i, plus(gn_bwd_quad<SWISH>(ld_stream(xn + i), ld_stream(dn + i), k, inv_m), i));
   } else {
     for (; i < per_n; i += stride) {
       gn_load_quad(s, n, i % s.quads, gamma, beta, mean, rstd, grp, k);
