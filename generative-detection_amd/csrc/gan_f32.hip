@@ -125,10 +125,15 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t rows, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wavefront per channel: the partials are summed lane-strided in f64, then by a fixed butterfly (deterministic).  One thread per
+  // channel walking all nblk partials was a chain of ~1 000 dependent loads: 125 us per launch for 4 KB of output.
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < nblk; ++k) { a += (double)part[((int64_t)k * 2 + 0) * C + c]; b += (double)part[((int64_t)k * 2 + 1) * C + c]; }
+  for (int k = lane; k < nblk; k += 64) { a += (double)part[((int64_t)k * 2 + 0) * C + c]; b += (double)part[((int64_t)k * 2 + 1) * C + c]; }
+  a = wave_sum_f64(a); b = wave_sum_f64(b);
+  if (lane != 0) return;
   const double m = (double)rows;
   const double mu = a / m;
   double var = b / m - mu * mu;
@@ -144,12 +149,14 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int
 
 // sums[2][C] = column totals of the partials (backward: sum g, sum g*xhat)
 __global__ void bn_sum_partials_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ sums) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;      // one wavefront per (which, channel), as bn_finalize_kernel
+  const int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (idx >= 2 * C) return;
   const int which = idx / C, c = idx % C;
   double a = 0.0;
-  for (int k = 0; k < nblk; ++k) a += (double)part[((int64_t)k * 2 + which) * C + c];
-  sums[idx] = (float)a;
+  for (int k = lane; k < nblk; k += 64) a += (double)part[((int64_t)k * 2 + which) * C + c];
+  a = wave_sum_f64(a);
+  if (lane == 0) sums[idx] = (float)a;
 }
 
 // y = lrelu((x-mean)*rstd*gamma+beta)
@@ -245,7 +252,7 @@ int odvae_batchnorm_lrelu_fwd_f32(const float* x, int64_t rows, int C, const flo
     const int rpb = (int)ceil_div64(rows, nblk);
     const int nb = (int)ceil_div64(rows, rpb);
     hipLaunchKernelGGL((bn_colstats_kernel<0>), dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, slope, rows, C, rpb, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, nb, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, part, nb, C, rows, eps, momentum, mean, rstd, running_mean, running_var);
   }
   hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3(grid_1d(rows * C)), dim3(256), 0, st, x, mean, rstd, gamma, beta, slope, rows * C, C, y);
   ODVAE_LAUNCH_CHECK("batchnorm_lrelu_fwd");
@@ -265,7 +272,7 @@ int odvae_batchnorm_lrelu_bwd_f32(const float* x, const float* dy, int64_t rows,
   const int nb = (int)ceil_div64(rows, rpb);
   float* sums = part + (size_t)nblk * 2 * C;
   hipLaunchKernelGGL((bn_colstats_kernel<1>), dim3(nb), dim3(256), 0, st, x, dy, mean, rstd, gamma, beta, slope, rows, C, rpb, part);
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, st, part, nb, C, sums);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, st, part, nb, C, sums);
   // dbeta = sum g ; dgamma = sum g*xhat
   hipMemcpyAsync(dbeta, sums, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
   hipMemcpyAsync(dgamma, sums + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
