@@ -309,9 +309,14 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, cons
       const int ci = (int)((idx / CoutP) % CinP);
       const int tap = (int)(idx / ((int64_t)CoutP * CinP));
       if (co < Cout && ci < Cin) {
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += slab[sp * per + idx];
-        dw[((int64_t)co * Cin + ci) * 9 + tap] = s;
+        float sk[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains: one chain of nsplit dependent round trips otherwise
+        int sp = 0;
+        for (; sp + 3 < nsplit; sp += 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sk[j] += slab[(sp + j) * per + idx];
+        }
+        for (; sp < nsplit; ++sp) sk[0] += slab[sp * per + idx];
+        dw[((int64_t)co * Cin + ci) * 9 + tap] = (sk[0] + sk[1]) + (sk[2] + sk[3]);
       }
     } else {
       const int co = (int)(idx - per);
@@ -474,16 +479,16 @@ __global__ void conv3x3_wgrad_up_reduce_kernel(const float* __restrict__ slab, c
         const int kh = tap / 3, kw = tap % 3;
         const int pa[2][2] = {{0, kh == 0 ? 0 : 1}, {1, kh == 2 ? 1 : 0}};   // (py, a) pairs for kh
         const int pb[2][2] = {{0, kw == 0 ? 0 : 1}, {1, kw == 2 ? 1 : 0}};   // (px, b) pairs for kw
-        float s = 0.f;
+        float sq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};      // one chain per (i, j) term: four loads in flight per split instead of one chain
         for (int sp = 0; sp < nsplit; ++sp)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int t16 = (pa[i][0] * 2 + pb[j][0]) * 4 + pa[i][1] * 2 + pb[j][1];
-              s += slab[((int64_t)sp * 16 + t16) * mat + (int64_t)ci * CoutP + co];
+              sq[i][j] += slab[((int64_t)sp * 16 + t16) * mat + (int64_t)ci * CoutP + co];
             }
-        dw[((int64_t)co * Cin + ci) * 9 + tap] = s;
+        dw[((int64_t)co * Cin + ci) * 9 + tap] = (sq[0][0] + sq[0][1]) + (sq[1][0] + sq[1][1]);
       }
     } else {
       const int co = (int)(idx - per);

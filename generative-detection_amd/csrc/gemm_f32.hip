@@ -515,8 +515,14 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
     const int batch = (int)(idx / mn);
     const int64_t rem = idx - (int64_t)batch * mn;
     const int row = (int)(rem / p.N), col = (int)(rem - (int64_t)row * p.N);
-    float s = 0.f;
-    for (int sp = 0; sp < p.splits; ++sp) s += p.partial[((int64_t)sp * batches + batch) * mn + rem];
+    float sk[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains (one chain of `splits` dependent round trips otherwise)
+    int sp = 0;
+    for (; sp + 3 < p.splits; sp += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sk[j] += p.partial[((int64_t)(sp + j) * batches + batch) * mn + rem];
+    }
+    for (; sp < p.splits; ++sp) sk[0] += p.partial[((int64_t)sp * batches + batch) * mn + rem];
+    float s = (sk[0] + sk[1]) + (sk[2] + sk[3]);
     s *= p.alpha;
     if (p.bias) s += p.bias[col];
     const int64_t o = batch * p.sC + (int64_t)row * p.ldc + col;
