@@ -246,7 +246,10 @@ class Decoder(nn.Module):
             z = ops.to_bf16(z)
         h = self.conv_in(z)
         recompute = self.activation_checkpoint and torch.is_grad_enabled() and h.requires_grad
-        run = (lambda f, t: torch.utils.checkpoint.checkpoint(f, t, use_reentrant=False)) if recompute else (lambda f, t: f(t))
+        def ckpt(f, t):      # (no GroupNorm-backward links inside a checkpointed unit: ops.GN_FUSED_BWD_SUSPENDED)
+            with ops.gn_fused_bwd_suspended():
+                return torch.utils.checkpoint.checkpoint(f, t, use_reentrant=False)
+        run = ckpt if recompute else (lambda f, t: f(t))
         # With the fused (bf16) attention an AttnBlock keeps only qkv, o and one f32 per row for its backward, so it stays OUTSIDE
         # the recomputed units: re-running the T x T products would cost far more than those tensors (3 of 8 attention forwards
         # per step at configs[4]).  The f32 path materialises P ([N, T, T]) and keeps attention inside the unit.

@@ -333,16 +333,28 @@ GN_GROUPS = 32      # Normalize() of the reference model: GroupNorm(32, C, eps 1
 # and of dy less).  ODVAE_GN_FUSED_BWD=0 turns it off.
 GN_FUSED_BWD = os.environ.get("ODVAE_GN_FUSED_BWD", "1") != "0"
 GN_FUSED_BWD_HITS = 0      # GroupNorm backwards that ran without their reduce pass (diagnostics, tests)
+GN_FUSED_BWD_SUSPENDED = 0  # > 0 inside an activation-checkpointed unit (modules.Decoder): a saved tensor of such a unit may be unpacked once per
+                            # backward, and the link would read the GroupNorm's from the conv's backward before the GroupNorm's own does
 
 
 class _GnBwdLink:
     """What the consumer conv's data gradient needs of the GroupNorm in front of it, and where it leaves the sums.  `out` identifies the
-    GroupNorm's output the way _gn_partials identifies a conv's: (data_ptr, version, shape)."""
-    __slots__ = ("x", "mean", "rstd", "gamma", "beta", "groups", "out", "sums")
+    GroupNorm's output the way _gn_partials identifies a conv's: (data_ptr, version, shape).  The GroupNorm's operands are NOT held here:
+    `node` is a weak reference to its autograd context, whose saved tensors (x, gamma, beta, mean, rstd) the conv's backward reads -- through
+    the saved-tensor hooks, so an activation-checkpointed unit recomputes them instead of this link keeping the first forward's alive."""
+    __slots__ = ("node", "groups", "out", "sums")
 
     def __init__(self):
-        self.x = self.mean = self.rstd = self.gamma = self.beta = self.out = self.sums = None
+        self.node = self.out = self.sums = None
         self.groups = 0
+
+    def operands(self):
+        """(x, mean, rstd, gamma, beta) of the GroupNorm, or None if its node is gone."""
+        ctx = self.node() if self.node is not None else None
+        if ctx is None:
+            return None
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        return x, mean, rstd, gamma.detach().contiguous(), beta.detach().contiguous()
 
     def take_sums(self, dy):
         """The sums, if they were made from exactly this gradient tensor (else None); single use."""
@@ -474,14 +486,15 @@ class _Conv3x3(Function):
                 du = _conv3x3_wino_raw(dy, dgr, cout, cin, None, None, f4=True)
                 dx = _new_cl(n, cin, hi, wi, x)
                 _lib.check(L.odvae_upsample2x_bwd_f32(du.data_ptr(), dx.data_ptr(), n, hi, wi, cin, _lib.stream_ptr()), "upsample2x_bwd")
-            elif ctx.up == "wino4" and ctx.gn_link is not None:
+            elif ctx.up == "wino4" and ctx.gn_link is not None and (gn_ops := ctx.gn_link.operands()) is not None:
                 # da and, from the same output transform, the first pass of the backward of the GroupNorm that produced this conv's input
                 lk = ctx.gn_link
+                gx, gmean, grstd, ggamma, gbeta = gn_ops
                 dx = _new_cl(n, cin, hi, wi, x)
                 sums = torch.empty(n, L.odvae_conv3x3_wino4_stats_chunks(hi, wi), 2, cin, dtype=torch.float32, device=x.device)
                 tag = KERNEL_EVENTS.begin()
-                _lib.check(L.odvae_conv3x3_wino4_gnbwd_f32(dy.data_ptr(), n, hi, wi, cout, dgr.data_ptr(), cin, dx.data_ptr(), lk.x.data_ptr(),
-                                                           lk.mean.data_ptr(), lk.rstd.data_ptr(), lk.gamma.data_ptr(), lk.beta.data_ptr(),
+                _lib.check(L.odvae_conv3x3_wino4_gnbwd_f32(dy.data_ptr(), n, hi, wi, cout, dgr.data_ptr(), cin, dx.data_ptr(), _cl(gx).data_ptr(),
+                                                           gmean.data_ptr(), grstd.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(),
                                                            lk.groups, sums.data_ptr(), _lib.stream_ptr()), "conv3x3_wino4_gnbwd")
                 KERNEL_EVENTS.end("conv3x3_wino4", 2.0 * 9 * cin * cout * n * hi * wi, tag, 4.0 * (n * hi * wi * (2 * cin + cout) + 9 * cin * cout),
                                   issued=2.0 * 2.25 * cin * cout * n * hi * wi, variant="data gradient + GroupNorm-backward sums")
@@ -862,7 +875,7 @@ class _GroupNorm(Function):
         ctx.set_materialize_grads(False)   # an unused output's gradient stays None instead of a tensor of zeros
         ctx.link = None
         if link is not None and swish:
-            link.x, link.mean, link.rstd, link.gamma, link.beta, link.groups = x.detach(), mean, rstd, g, b, groups
+            link.node, link.groups = weakref.ref(ctx), groups
             ctx.link = link
         if with_skip:
             return y, x.view_as(x)   # the skip connection's handle on x: its gradient comes back into this node
@@ -919,11 +932,25 @@ def _gn_partials_of(x, groups):
 
 
 def _f32_gn_link(x, groups, swish):
-    return _GnBwdLink() if (GN_FUSED_BWD and swish and groups == GN_GROUPS and torch.is_grad_enabled() and x.requires_grad) else None
+    ok = GN_FUSED_BWD and not GN_FUSED_BWD_SUSPENDED and swish and groups == GN_GROUPS and torch.is_grad_enabled() and x.requires_grad
+    return _GnBwdLink() if ok else None
+
+
+class gn_fused_bwd_suspended:
+    """Context manager: no GroupNorm-backward links for the forward calls inside (activation-checkpointed units)."""
+
+    def __enter__(self):
+        global GN_FUSED_BWD_SUSPENDED
+        GN_FUSED_BWD_SUSPENDED += 1
+
+    def __exit__(self, *exc):
+        global GN_FUSED_BWD_SUSPENDED
+        GN_FUSED_BWD_SUSPENDED -= 1
+        return False
 
 
 def _tag_gn_output(y, link):
-    if link is not None and link.x is not None:
+    if link is not None and link.node is not None:
         link.out = (y.data_ptr(), y._version, tuple(y.shape))
         y._gn_bwd_link = link
     return y
