@@ -143,7 +143,9 @@ class _PackCache:
 
     def get(self, weight, want_dgrad, up=False):
         key = (id(weight), up)
-        tag = (weight.data_ptr(), weight._version, self.epoch)
+        # (a frozen weight -- the LPIPS-style VGG stack -- is in no optimizer: its packs do not go stale with the optimizer epoch, only with a
+        # write to the tensor itself (load_state_dict: version counter))
+        tag = (weight.data_ptr(), weight._version, self.epoch if weight.requires_grad else -1)
         hit = self.store.get(key)
         same = hit is not None and hit[0]() is weight
         if same and hit[1] == tag and (hit[3] is not None or not want_dgrad):
@@ -182,7 +184,7 @@ class _PackCache:
             w = ent[0]()
             if w is None or w.device != device or ent[4] != (tuple(w.shape), w.device) or not w.is_contiguous() or w.dtype != torch.float32:
                 continue
-            tag = (w.data_ptr(), w._version, self.epoch)
+            tag = (w.data_ptr(), w._version, self.epoch if w.requires_grad else -1)
             if ent[1] == tag or not _batchable(kind, w, L):
                 continue
             live.append((key, ent, w, tag))
