@@ -135,17 +135,27 @@ class _PackCache:
 
     def __init__(self):
         self.epoch = 0
+        self._trainable = set()
         self.store = {}
         self._tables = {}
 
     def bump(self):
         self.epoch += 1
 
+    def _epoch_of(self, weight):
+        """The optimizer epoch a pack of this weight is valid for, or -1 for a weight that has never been trainable while this cache saw it
+        (a tensor whose requires_grad is only switched off for a while -- the discriminator during the generator phase -- is still updated
+        by its optimizer without a version bump)."""
+        if weight.requires_grad:
+            self._trainable.add(id(weight))
+            return self.epoch
+        return self.epoch if id(weight) in self._trainable else -1
+
     def get(self, weight, want_dgrad, up=False):
         key = (id(weight), up)
         # (a frozen weight -- the LPIPS-style VGG stack -- is in no optimizer: its packs do not go stale with the optimizer epoch, only with a
         # write to the tensor itself (load_state_dict: version counter))
-        tag = (weight.data_ptr(), weight._version, self.epoch if weight.requires_grad else -1)
+        tag = (weight.data_ptr(), weight._version, self._epoch_of(weight))
         hit = self.store.get(key)
         same = hit is not None and hit[0]() is weight
         if same and hit[1] == tag and (hit[3] is not None or not want_dgrad):
@@ -184,7 +194,7 @@ class _PackCache:
             w = ent[0]()
             if w is None or w.device != device or ent[4] != (tuple(w.shape), w.device) or not w.is_contiguous() or w.dtype != torch.float32:
                 continue
-            tag = (w.data_ptr(), w._version, self.epoch if w.requires_grad else -1)
+            tag = (w.data_ptr(), w._version, self._epoch_of(w))
             if ent[1] == tag or not _batchable(kind, w, L):
                 continue
             live.append((key, ent, w, tag))
