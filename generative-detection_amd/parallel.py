@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False, comm_dtype=None):
+    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False, comm_dtype=None, f32_accumulate=False):
         """prescaled=True: the caller back-propagates `loss * inv_world` (trainer.Trainer does), so the summed buckets
         already ARE the mean and finish() needs no averaging pass over the arena (284 MB for optimizer 0).
         comm_dtype=torch.bfloat16: a bucket travels as bf16 -- cast into a staging buffer when its last gradient lands, all-reduced
@@ -24,10 +24,18 @@ class GradReducer:
         step).  For the bf16 step, whose backward is a third as long as the f32 one: with the default f32 buckets the
         exchange is 3-4 % of that step unless fully hidden.  The mean of world <= 8 bf16-rounded, pre-scaled gradients carries a
         relative error of about 2^-9 per element, the size of the rounding the bf16 activations already put into them; master
-        weights, Adam moments and the clip norm stay f32."""
+        weights, Adam moments and the clip norm stay f32.
+        f32_accumulate=True (with comm_dtype bf16; SURVEY.md 5 "reduce-scatter with f32 accumulation"): instead of one bf16 all-reduce
+        (whose partial sums are rounded to bf16 at every hop of the ring), a bucket is exchanged in two halves of the same traffic --
+        all-to-all of its world-many shards (rank r receives shard r of every rank, as bf16), the world shards summed in f32 on the rank
+        that owns them, ONE rounding of the sum to bf16, all-gather of the reduced shards.  The second half of a bucket is issued when the
+        next bucket starts (or in finish()), so both halves overlap with the rest of the backward pass.  Backends without all-to-all
+        (gloo, in the CPU tests) take the same arithmetic through all-gathers."""
         self.group = process_group
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self.f32_accumulate = bool(f32_accumulate) and self.comm_dtype is not None
         self._staging = {}
+        self._stage2 = []        # f32_accumulate: (bucket, work of its all-to-all) waiting for the local sum + all-gather
         self.world = dist.get_world_size(process_group)
         self.inv_world = 1.0 / self.world
         self.prescaled = bool(prescaled)
@@ -86,6 +94,7 @@ class GradReducer:
         # gradients are gathered into the arena right before its collective (`_launch`)
         self._pending = list(self.bucket_size)
         self._works = []
+        self._stage2 = []
         self._launched = set()
         self._touched_buckets = set()
         self.launch_order = []
@@ -108,11 +117,53 @@ class GradReducer:
         if self.comm_dtype is None:
             self._works.append(dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if self.f32_accumulate:
+                self._second_halves()                   # the buckets issued before this one: sum + all-gather, under the backward still running
+                self._first_half(b)
+                return
             buf = self._staging.get(b)
             if buf is None:
                 buf = self._staging[b] = torch.empty(e - s, dtype=self.comm_dtype, device=self.arena.device)
             buf.copy_(self.arena[s:e])                  # f32 -> bf16, one pass over the bucket
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    # ---- bf16 on the wire, f32 sums (f32_accumulate) ----------------------------------------------------------------------
+    def _shards(self, b):
+        s, e = self.buckets[b]
+        shard = (e - s + self.world - 1) // self.world
+        return s, e, shard
+
+    def _first_half(self, b):
+        s, e, shard = self._shards(b)
+        st = self._staging.get(("a2a", b))
+        if st is None:
+            dev = self.arena.device
+            st = self._staging[("a2a", b)] = {"send": torch.zeros(self.world * shard, dtype=self.comm_dtype, device=dev),
+                                              "recv": torch.empty(self.world * shard, dtype=self.comm_dtype, device=dev),
+                                              "red": torch.empty(shard, dtype=self.comm_dtype, device=dev),
+                                              "out": torch.empty(self.world * shard, dtype=self.comm_dtype, device=dev)}
+        st["send"][:e - s].copy_(self.arena[s:e])       # f32 -> bf16 (the padding past the bucket stays 0)
+        if dist.get_backend(self.group) == "gloo":      # no all-to-all there: every rank gets everything and keeps its own shard of each
+            parts = [torch.empty_like(st["send"]) for _ in range(self.world)]
+            w = dist.all_gather(parts, st["send"], group=self.group, async_op=True)
+            st["parts"] = parts
+        else:
+            w = dist.all_to_all_single(st["recv"], st["send"], group=self.group, async_op=True)
+        self._stage2.append((b, w))
+
+    def _second_halves(self):
+        rank = dist.get_rank(self.group)
+        for b, w in self._stage2:
+            w.wait()                                    # (a stream dependency on the collective, not a host wait, under RCCL)
+            s, e, shard = self._shards(b)
+            st = self._staging[("a2a", b)]
+            if "parts" in st and dist.get_backend(self.group) == "gloo":
+                mine = torch.stack([q[rank * shard:(rank + 1) * shard] for q in st["parts"]])
+            else:
+                mine = st["recv"].view(self.world, shard)
+            st["red"].copy_(mine.float().sum(dim=0))    # world shards summed in f32, rounded to bf16 once
+            self._works.append(dist.all_gather_into_tensor(st["out"], st["red"], group=self.group, async_op=True))
+        self._stage2 = []
 
     def finish(self):
         """Issue the collectives of buckets that only some of their parameters reached (same set on every rank,
@@ -120,12 +171,15 @@ class GradReducer:
         pre-scaled by 1/world (`prescaled`); otherwise the reduced buckets are averaged here."""
         for b in sorted(self._touched_buckets - self._launched, reverse=True):
             self._launch(b)
+        if self.f32_accumulate:
+            self._second_halves()
         for w in self._works:
             w.wait()
         if self.comm_dtype is not None:
             for b in self.launch_order:
                 s, e = self.buckets[b]
-                self.arena[s:e].copy_(self._staging[b])   # bf16 -> f32 back into the arena
+                src = self._staging[("a2a", b)]["out"][:e - s] if self.f32_accumulate else self._staging[b]
+                self.arena[s:e].copy_(src)                # bf16 -> f32 back into the arena
         if not self.prescaled:
             for b in self.launch_order:
                 s, e = self.buckets[b]

@@ -24,7 +24,7 @@ class _TrainerHandle:
 
 class Trainer:
     def __init__(self, model, gradient_clip_val=None, optimizer_indices=(0, 1), process_group=None, bucket_mb=None, precision=None,
-                 distributed=None, comm_dtype=None, callbacks=(), logger=None):
+                 distributed=None, comm_dtype=None, callbacks=(), logger=None, comm_f32_accumulate=False):
         """optimizer_indices: which of the model's optimizers run each batch; (0,) is the "rec+KL only" benchmark
         configuration (discriminator off, optimizer 1 skipped -- SURVEY.md 8(d)).
         comm_dtype: dtype of the gradient buckets on the wire; None = f32 in every precision -- what the reference's `strategy: ddp`
@@ -64,7 +64,7 @@ class Trainer:
             # the mean over ranks rides in the loss scale (training_batch), not in a pass over the gradient arena
             if bucket_mb is None:
                 bucket_mb = 16.0 if comm_dtype == torch.bfloat16 else 32.0
-            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb, prescaled=True, comm_dtype=comm_dtype)
+            self.reducers = [GradReducer(o, process_group=process_group, bucket_mb=bucket_mb, prescaled=True, comm_dtype=comm_dtype, f32_accumulate=comm_f32_accumulate)
                              for o in opts]
             self.reducers[0].broadcast_parameters(model)
 

@@ -131,12 +131,18 @@ def _nccl_worker(rank, world, port, out_dir):
     from odvae_amd import synthetic
     from odvae_amd.trainer import Trainer
     runs = {}
-    for mode in ("rccl", "single"):
+    for mode in ("rccl", "single", "rccl-bf16-f32acc"):
         torch.manual_seed(23)
         model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32).to("cuda:0").train()
         if mode == "rccl":
             trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), process_group=dist.group.WORLD, bucket_mb=1.0)
             assert trainer.reducers is not None and dist.get_backend() == "nccl"
+        elif mode == "rccl-bf16-f32acc":
+            # bf16 buckets with f32 accumulation: all_to_all_single + all_gather_into_tensor of RCCL itself (world size 1: the sum of one
+            # shard is that shard, so every gradient is exactly its own bf16 rounding)
+            trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), process_group=dist.group.WORLD, bucket_mb=1.0,
+                              comm_dtype=torch.bfloat16, comm_f32_accumulate=True)
+            assert trainer.reducers[0].f32_accumulate
         else:
             trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), distributed=False)
             assert trainer.reducers is None
@@ -148,7 +154,7 @@ def _nccl_worker(rank, world, port, out_dir):
             losses.append(trainer.training_batch(batch, step)[0].item())
         torch.cuda.synchronize()
         runs[mode] = {"sd": {k: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith(OWNED)}, "losses": losses}
-        if mode == "rccl":
+        if mode.startswith("rccl"):
             red = trainer.reducers[0]
             runs[mode].update(nbuckets=len(red.buckets), order=list(red.launch_order))
         del model, trainer
@@ -207,3 +213,11 @@ def test_rccl_world1_step_is_bit_identical_to_single_process(tmp_path):
     assert a["losses"] == b["losses"], (a["losses"], b["losses"])
     for k in b["sd"]:
         assert torch.equal(a["sd"][k], b["sd"][k]), k
+    # bf16 buckets, f32-accumulated, through RCCL's all-to-all / all-gather: every bucket travelled; the first step's loss is the same
+    # (the exchange comes after it), the second differs by what two Adam steps on bf16-rounded gradients can move the weights
+    c = runs["rccl-bf16-f32acc"]
+    assert c["nbuckets"] >= 2 and sorted(c["order"]) == list(range(c["nbuckets"]))
+    assert c["losses"][0] == b["losses"][0] and abs(c["losses"][1] - b["losses"][1]) <= 2e-3 * abs(b["losses"][1])
+    lr = 4.5e-6 * 12
+    for k in b["sd"]:
+        assert (c["sd"][k] - b["sd"][k]).abs().max().item() <= 2 * 2.2 * lr + 1e-6, k

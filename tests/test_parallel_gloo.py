@@ -106,6 +106,16 @@ def _worker(rank, world, port, out_dir):
     net3(full_x[shard]).pow(2).mean().backward()
     red3.finish()
     g3 = torch.cat([p.grad.reshape(-1) for p in net3.parameters()]).clone()
+    # bf16 on the wire with f32 accumulation: all-to-all of shards -> f32 sum on the owning rank -> one rounding -> all-gather
+    net5 = TinyNet()
+    opt5 = torch.optim.SGD(net5.parameters(), lr=0.1)
+    red5 = GradReducer(opt5, bucket_mb=0.02, comm_dtype=torch.bfloat16, f32_accumulate=True)
+    red5.broadcast_parameters(net5)
+    red5.prepare_for_backward()
+    net5(full_x[shard]).pow(2).mean().backward()
+    local5 = torch.cat([p.grad.reshape(-1) for p in net5.parameters()]).clone()      # this rank's own gradient (the arena, before the exchange)
+    red5.finish()
+    g5 = torch.cat([p.grad.reshape(-1) for p in net5.parameters()]).clone()
     # the same through the Trainer: comm_dtype=torch.bfloat16 is an opt-in (the default keeps f32 buckets, whatever the precision)
     assert all(r.comm_dtype is None for r in trainer.reducers)
     torch.manual_seed(300 + rank)
@@ -119,7 +129,8 @@ def _worker(rank, world, port, out_dir):
     red4.finish()
     grads4 = {n: p.grad.clone() for n, p in model4.gen.named_parameters()}
     sd4 = {k: v.clone() for k, v in model4.state_dict().items()}
-    torch.save({"grads4": grads4, "sd4": sd4, "g3": g3, "sd3": net3.state_dict(), "nb3": len(red3.buckets), "order3": list(red3.launch_order), "synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
+    torch.save({"g5": g5, "local5": local5, "nb5": len(red5.buckets),
+                "grads4": grads4, "sd4": sd4, "g3": g3, "sd3": net3.state_dict(), "nb3": len(red3.buckets), "order3": list(red3.launch_order), "synced": synced, "local": local, "g2": g2, "sd2": net2.state_dict(), "grads": grads, "sd0": sd0, "sd": model.state_dict(), "order": order, "nbuckets": len(red.buckets),
                 "global_step": model._global_step}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -173,3 +184,8 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     assert torch.equal(r0["g3"], r1["g3"])
     assert (r0["g3"] - want3).abs().max().item() <= 2.0 ** -6 * want3.abs().max().item()
     assert not torch.equal(r0["g3"], want3)          # it really went through bf16
+    # bf16 on the wire, f32 sums: EXACTLY bf16(mean-less sum in f32 of the two bf16-rounded shard gradients) averaged by the generic
+    # reducer's finish() -- one rounding of the sum, not one per hop
+    assert r0["nb5"] >= 2 and torch.equal(r0["g5"], r1["g5"])
+    exact5 = (r0["local5"].to(torch.bfloat16).float() + r1["local5"].to(torch.bfloat16).float()).to(torch.bfloat16).float() * 0.5
+    assert torch.equal(r0["g5"], exact5)
