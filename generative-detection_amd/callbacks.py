@@ -62,8 +62,10 @@ class ImageLogger(Callback):
     no_grad (on the device: the same HIP kernels as the training step's forward), at most `max_images` images per key come to the host,
     are clamped to [-1, 1], and each key is written as `<save_dir>/images/<split>/<key>_gs-<global_step:06>_e-<epoch:06>_b-<batch:06>.png`
     (4 images per row, [-1, 1] -> [0, 255]).  Schedule: steps 1, 2, 4, ..., 2^floor(log2(batch_frequency)) once each, and every
-    multiple of `batch_frequency`; never at step 0 unless `log_first_step`.  `logger_log_images` (TensorBoard in the reference) is a
-    hook table keyed by logger type; it is empty here, so only the local PNGs are written."""
+    multiple of `batch_frequency`; never at step 0 unless `log_first_step`.  `logger_log_images` is the reference's hook table keyed by logger
+    type (callbacks.py:115-117: `pl.loggers.TensorBoardLogger -> _testtube`): `_testtube` is here too, registered for
+    `pytorch_lightning.loggers.TensorBoardLogger` where that package is importable and taken for any logger whose class is NAMED
+    TensorBoardLogger and whose `experiment` has `add_image` (torch.utils.tensorboard.SummaryWriter's signature) otherwise."""
 
     def __init__(self, batch_frequency, max_images, clamp=True, increase_log_steps=True, rescale=True, disabled=False,
                  log_on_batch_idx=False, log_first_step=False, log_images_kwargs=None, disable_local_logging=False):
@@ -72,6 +74,11 @@ class ImageLogger(Callback):
         self.batch_freq = batch_frequency
         self.max_images = max_images
         self.logger_log_images = {}
+        try:      # the reference's table (callbacks.py:115-117), where Lightning is there to key it
+            from pytorch_lightning.loggers import TensorBoardLogger as _TB
+            self.logger_log_images[_TB] = self._testtube
+        except Exception:  # noqa: BLE001
+            pass
         self.log_steps = [2 ** n for n in range(int(np.log2(self.batch_freq)) + 1)]
         if not increase_log_steps:
             self.log_steps = [self.batch_freq]
@@ -81,6 +88,15 @@ class ImageLogger(Callback):
         self.log_images_kwargs = log_images_kwargs if log_images_kwargs else {}
         self.log_first_step = log_first_step
         self.disable_local_logging = disable_local_logging
+
+    def _testtube(self, pl_module, images, batch_idx, split):
+        """callbacks.py:128-139: one grid per key (make_grid's default 8 per row, [-1, 1] -> [0, 1]) into `logger.experiment.add_image`."""
+        if not _is_rank_zero():
+            return
+        for k in images:
+            grid = make_grid(images[k])
+            grid = (grid + 1.0) / 2.0
+            pl_module.logger.experiment.add_image("%s/%s" % (split, k), grid, global_step=pl_module.global_step)
 
     def log_local(self, save_dir, split, images, global_step, current_epoch, batch_idx):
         from PIL import Image
@@ -121,6 +137,8 @@ class ImageLogger(Callback):
             save_dir = getattr(logger, "save_dir", None) or "."
             written = self.log_local(save_dir, split, images, pl_module.global_step, getattr(pl_module, "current_epoch", 0), batch_idx)
         hook = self.logger_log_images.get(type(logger))
+        if hook is None and type(logger).__name__ == "TensorBoardLogger" and hasattr(getattr(logger, "experiment", None), "add_image"):
+            hook = self._testtube
         if hook is not None:
             hook(pl_module, images, pl_module.global_step, split)
         if is_train:

@@ -71,6 +71,41 @@ def test_image_logger_schedule_files_and_pixels(tmp_path):
     assert sorted(os.listdir(os.path.join(tmp_path, "images", "val")))[0] == "inputs_rgb_gs-000030_e-000003_b-000007.png"
 
 
+def test_image_logger_tensorboard_hook(tmp_path):
+    """The reference's `logger_log_images` table (src/util/callbacks.py:115-117, 128-139): with a TensorBoard logger every logged key also
+    goes to `logger.experiment.add_image(f"{split}/{key}", grid in [0, 1], global_step=...)`, one grid (make_grid, 8 per row) per key."""
+    from odvae_amd.callbacks import ImageLogger, make_grid
+
+    class Experiment:
+        def __init__(self):
+            self.images = []
+
+        def add_image(self, tag, img, global_step=None):
+            self.images.append((tag, img.clone(), global_step))
+
+    class TensorBoardLogger:       # (what pytorch_lightning.loggers.TensorBoardLogger looks like to the callback)
+        def __init__(self, save_dir):
+            self.save_dir, self.experiment = save_dir, Experiment()
+
+    m = FakeModule(str(tmp_path))
+    m.logger = TensorBoardLogger(str(tmp_path))
+    cb = ImageLogger(batch_frequency=4, max_images=5, clamp=True)
+    m.global_step = 2
+    cb.on_train_batch_end(None, m, None, {}, 0)
+    got = m.logger.experiment.images
+    assert [t for t, _, _ in got] == ["train/inputs_rgb", "train/reconstructions_rgb"] and all(gs == 2 for _, _, gs in got)
+    g = torch.Generator().manual_seed(2)
+    want = (make_grid(torch.clamp(torch.rand(5, 3, 6, 4, generator=g) * 3 - 1.5, -1.0, 1.0)) + 1.0) / 2.0
+    assert torch.allclose(got[0][1], want) and got[0][1].min() >= 0.0 and got[0][1].max() <= 1.0
+    assert any(f.endswith(".png") for _, _, fs in os.walk(str(tmp_path)) for f in fs)      # the local files are written as well
+    # a logger that is not a TensorBoard logger gets nothing
+    m2 = FakeModule(str(tmp_path / "other"))
+    m2.logger.experiment = Experiment()
+    m2.global_step = 2
+    ImageLogger(batch_frequency=4, max_images=5).on_train_batch_end(None, m2, None, {}, 0)
+    assert m2.logger.experiment.images == []
+
+
 def test_yaml_callbacks_resolve():
     from odvae_amd.config import Config, instantiate_from_config
     cfg = Config.load(YAML)
