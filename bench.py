@@ -49,6 +49,9 @@ def parse():
                     help="BASELINE.json configs[4]: bf16 mixed precision (bf16 activations in HBM, fp32 master weights and accumulation)")
     ap.add_argument("--ckpt-decoder", action="store_true",
                     help="BASELINE.json configs[4]: activation-checkpointed Decoder (each up level / mid block is recomputed in backward)")
+    ap.add_argument("--ckpt-policy", choices=("unit", "norm"), default="unit",
+                    help="with --ckpt-decoder: unit = torch.utils.checkpoint per ResnetBlock(+AttnBlock) (BASELINE.json configs[4]); norm = keep the conv "
+                         "outputs, re-make only the GroupNorm+swish tensors in the backward (modules.Decoder)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on one GPU: initialise RCCL with world size 1 and run the bucketed reducer anyway")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -275,7 +278,7 @@ def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False, force_d
         lat = res // 16
         gkw = dict(perceptual_weight=1.0, disc_factor=1.0, disc_start=0) if gan else {}
         model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gkw).to(dev).train()
-        model.decoder.activation_checkpoint = bool(ckpt)
+        model.decoder.activation_checkpoint = ckpt if ckpt in ("unit", "norm") else bool(ckpt)
         model._global_step = 1
         group = None
         if force_dist:
@@ -434,7 +437,7 @@ def main():
     model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=lat, **gan).to(dev)
     model.train()
     if args.ckpt_decoder:
-        model.decoder.activation_checkpoint = True
+        model.decoder.activation_checkpoint = args.ckpt_policy
     # --bf16: the trainer's `precision: bf16` (yaml:139) -- bf16 activations on the bf16 MFMA kernels + fused attention, f32 master
     # weights; with N > 1 the gradient buckets then travel as bf16 too (parallel.GradReducer)
     # steady state: past the very first optimizer step, whose total holds the pose terms only (`global_step >
@@ -538,7 +541,7 @@ def main():
                        % (args.res, args.res, args.batch,
                           ("PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if args.gan
                            else "rec+KL only (discriminator off, optimizer 0)")
-                          + (", activation-checkpointed Decoder" if args.ckpt_decoder else "")
+                          + ((", activation-checkpointed Decoder" + (" (norm policy)" if args.ckpt_policy == "norm" else "")) if args.ckpt_decoder else "")
                           + (", bf16 mixed precision (bf16 activations, f32 master weights / accumulation)" if args.bf16 else ", fp32")),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         }
@@ -643,6 +646,8 @@ def main():
             oc = {}
             oc["configs[1] shape (256x256, B=32) in bf16 mixed precision"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
             oc["configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder"] = side_run(dev, 512, 32, 4, 2, True, "bf16")
+            oc["configs[4] geometry with the 'norm' checkpoint policy (conv outputs kept, only GroupNorm+swish re-made in the backward: more memory, "
+               "less recompute; NOT the unit-checkpointed configuration of the line above)"] = side_run(dev, 512, 32, 4, 2, "norm", "bf16")
             oc["configs[3] 256x256 B=32 fp32, PatchGAN discriminator + LPIPS-style loss, both optimizers"] = side_run(dev, 256, 32, 4, 2, False, 32, gan=True)
             oc["configs[1] shape in bf16, repeated after the 512x512 and GAN runs"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
             # the data-parallel path's overhead is the difference between THESE two adjacent runs (the headline ran first, on a cooler chip

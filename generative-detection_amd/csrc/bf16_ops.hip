@@ -349,6 +349,19 @@ int odvae_groupnorm_fwd_partials_bf16(const void* x, int N, int HW, int C, int G
   return ODVAE_OK;
 }
 
+// The apply pass alone with mean / rstd given (odvae_groupnorm_apply_f32's bf16 twin)
+int odvae_groupnorm_apply_bf16(const void* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, int swish, void* y, void* stream) {
+  GnB s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_apply_bf16: unsupported shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && gamma && beta && y && mean && rstd, "groupnorm_apply_bf16: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "groupnorm_apply_bf16: misaligned operand");
+  hipLaunchKernelGGL(gnb_apply_kernel, dim3(apply_blocks(s), N), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x), s,
+                     gamma, beta, mean, rstd, swish, static_cast<bf16_t*>(y));
+  ODVAE_LAUNCH_CHECK("groupnorm_apply_bf16");
+  return ODVAE_OK;
+}
+
 // dx bf16 (+ dx_add bf16, the folded skip gradient, or NULL), dgamma / dbeta f32 [C]
 int odvae_groupnorm_bwd_bf16(const void* x, const void* dy, int N, int HW, int C, int G, const float* gamma, const float* beta,
                              const float* mean, const float* rstd, int swish, void* dx, float* dgamma, float* dbeta, const void* dx_add,

@@ -592,6 +592,23 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
   return ODVAE_OK;
 }
 
+// The apply pass alone, with mean / rstd given (as a forward call left them): y = act(GroupNorm(x)) re-made from x -- the recompute of
+// the "norm" activation-checkpoint policy (modules.py: the conv that consumed y keeps (x, mean, rstd) instead of y).
+int odvae_groupnorm_apply_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                              const float* mean, const float* rstd, int swish, float* y, void* stream) {
+  GnShape s;
+  ODVAE_CHECK_ARG(make_shape(N, HW, C, G, s), "groupnorm_apply: unsupported shape N=%d HW=%d C=%d G=%d", N, HW, C, G);
+  ODVAE_CHECK_ARG(x && gamma && beta && y && mean && rstd, "groupnorm_apply: null operand");
+  ODVAE_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0,
+                  "groupnorm_apply: operands must be 16-byte aligned");
+  const dim3 grid(apply_blocks(s), N);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (swish) hipLaunchKernelGGL((gn_apply_kernel<true>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  else       hipLaunchKernelGGL((gn_apply_kernel<false>), grid, dim3(256), 0, st, x, s, gamma, beta, mean, rstd, y);
+  ODVAE_LAUNCH_CHECK("groupnorm apply");
+  return ODVAE_OK;
+}
+
 // The same with the statistics pass already done by the kernel that produced x: partial [N][chunks][G][2] = (sum, sum of squares) of x
 // per chunk and channel group (odvae_conv3x3_wino4_stats_f32 writes one chunk per output tile).  Two launches instead of three: finalize
 // (f64, fixed order over the chunks) + apply; x is read once.

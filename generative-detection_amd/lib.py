@@ -65,6 +65,8 @@ PROTOTYPES = {
     "odvae_groupnorm_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "odvae_groupnorm_fwd_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_fwd_partials_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P, _I, _P]),
+    "odvae_groupnorm_apply_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "odvae_groupnorm_apply_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "odvae_groupnorm_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "odvae_groupnorm_bwd_partials_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "odvae_groupnorm_select_backward": (_I, [_I]),

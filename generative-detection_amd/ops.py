@@ -986,6 +986,54 @@ def group_norm_skip(x, gamma, beta, groups=32, eps=1e-6, swish=False):
     return _tag_gn_output(y, link), skip
 
 
+# "norm" activation-checkpoint policy: the tensor a = act(GroupNorm(x)) is NOT kept for the backward of the conv that consumes it; that conv's
+# saved input is replaced (saved-tensor hooks) by what it takes to re-make it -- x, mean, rstd, gamma, beta -- and one apply pass rebuilds it when
+# the conv's backward asks for its saved tensors.  Against the unit policy (torch.utils.checkpoint around a whole ResnetBlock) nothing but the
+# GroupNorm apply is recomputed: no conv, no attention forward runs twice.
+def group_norm_apply(x, gamma, beta, mean, rstd, groups, swish):
+    """act(GroupNorm(x)) from a forward call's statistics (no autograd): the recompute of the "norm" policy."""
+    L = _L()
+    x = _cl(x, x.dtype if x.dtype == BF16 else torch.float32)
+    n, c, h, w = x.shape
+    y = _new_cl(n, c, h, w, x, dtype=x.dtype)
+    fn = L.odvae_groupnorm_apply_bf16 if x.dtype == BF16 else L.odvae_groupnorm_apply_f32
+    _lib.check(fn(x.data_ptr(), n, h * w, c, int(groups), gamma.detach().contiguous().data_ptr(), beta.detach().contiguous().data_ptr(),
+                  mean.data_ptr(), rstd.data_ptr(), int(swish), y.data_ptr(), _lib.stream_ptr()), "groupnorm_apply")
+    return y
+
+
+class _RemakeFromNorm:
+    __slots__ = ("x", "gamma", "beta", "mean", "rstd", "groups", "swish")
+
+    def __init__(self, node):
+        self.x, self.gamma, self.beta, self.mean, self.rstd = node.saved_tensors
+        self.groups, self.swish = node.groups, node.swish
+
+    def make(self):
+        with torch.no_grad():
+            return group_norm_apply(self.x, self.gamma, self.beta, self.mean, self.rstd, self.groups, self.swish)
+
+
+class remake_from_norm(torch.autograd.graph.saved_tensors_hooks):
+    """with remake_from_norm(a): y = conv(a) -- `a` must be the output of ops.group_norm / group_norm_skip (its grad_fn holds x, mean, rstd)."""
+
+    def __init__(self, a):
+        node = a.grad_fn
+        ok = node is not None and hasattr(node, "groups") and hasattr(node, "swish") and len(getattr(node, "saved_tensors", ())) == 5
+        key = (a.data_ptr(), tuple(a.shape), a.dtype) if ok else None
+        recipe = _RemakeFromNorm(node) if ok else None
+
+        def pack(t):
+            if key is not None and t.data_ptr() == key[0] and tuple(t.shape) == key[1] and t.dtype == key[2]:
+                return recipe
+            return t
+
+        def unpack(obj):
+            return obj.make() if isinstance(obj, _RemakeFromNorm) else obj
+
+        super().__init__(pack, unpack)
+
+
 # ------------------------------------------------------------------------------------------------------
 # input rescale, posterior, reconstruction term
 # ------------------------------------------------------------------------------------------------------

@@ -163,6 +163,12 @@ int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const f
 int odvae_groupnorm_fwd_partials_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
                                      float eps, int swish, float* y, float* mean, float* rstd,
                                      const float* partial, int chunks, void* stream);
+/* the apply pass alone from a forward call's mean / rstd: y = act(GroupNorm(x)) re-made from x (the recompute of the "norm" checkpoint policy:
+ * the conv that consumed y keeps (x, mean, rstd) instead of y); odvae_groupnorm_apply_bf16 is its bf16 twin */
+int odvae_groupnorm_apply_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                              const float* mean, const float* rstd, int swish, float* y, void* stream);
+int odvae_groupnorm_apply_bf16(const void* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
+                               const float* mean, const float* rstd, int swish, void* y, void* stream);
 int odvae_groupnorm_bwd_f32(const float* x, const float* dy, int N, int HW, int C, int G,
                             const float* gamma, const float* beta, const float* mean, const float* rstd, int swish,
                             float* dx, float* dgamma, float* dbeta, const float* dx_add,

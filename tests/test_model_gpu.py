@@ -33,7 +33,7 @@ def build_pair(perceptual_weight=0.0, disc_factor=0.0, latent_hw=4, activation_c
     mcfg, cfg = synthetic.model_config(YAML, latent_hw=latent_hw, ch=ch, perceptual_weight=perceptual_weight,
                                        disc_factor=disc_factor, phase=phase)
     if activation_checkpoint:
-        mcfg.params.ddconfig["activation_checkpoint"] = True
+        mcfg.params.ddconfig["activation_checkpoint"] = activation_checkpoint
     model = instantiate_from_config(mcfg)
     model.learning_rate = 12 * cfg.model.base_learning_rate
     p = mcfg.params.to_container()
@@ -282,6 +282,37 @@ def test_decoder_recompute_is_bit_identical(hip_lib):
     assert g0.keys() == g1.keys() and g0["decoder.conv_in.weight"].abs().max().item() > 0
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("precision", [None, "bf16"], ids=["f32", "bf16"])
+def test_decoder_norm_checkpoint_policy_is_bit_identical_and_saves_memory(hip_lib, precision):
+    """ddconfig.activation_checkpoint = "norm": the convs of the decoder keep (x, mean, rstd) of the Normalize in front of them instead of its
+    normalised + activated output and re-make that tensor with one GroupNorm apply pass in their backward (ops.remake_from_norm).  Same kernels
+    on the same values: loss and every gradient bit-identical to the plain model; the peak memory of forward + backward is lower."""
+    from odvae_amd import synthetic
+    plain, _ = build_pair(ch=64, latent_hw=8)
+    norm, _ = build_pair(ch=64, latent_hw=8, activation_checkpoint="norm")
+    norm.load_state_dict(plain.state_dict())
+    assert norm.decoder.activation_checkpoint == "norm"
+    if precision:
+        plain.set_precision(precision); norm.set_precision(precision)
+    plain.train(); norm.train()
+    batch = synthetic.make_batch(4, 128, seed=5)
+    noise = synthetic.make_noise(4, 8, dropout_p=0.7, seed=6)
+    peaks = []
+    outs = []
+    for m in (plain, norm):
+        torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        outs.append(_step_with_grads(m, batch, noise))
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - base)
+    (l0, g0), (l1, g1) = outs
+    assert torch.equal(l0, l1)
+    assert g0.keys() == g1.keys() and g0["decoder.conv_in.weight"].abs().max().item() > 0
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert peaks[1] < 0.93 * peaks[0], peaks        # (the encoder's activations and the losses are untouched: the step's peak falls by the decoder's share)
 
 
 def test_config5_geometry_512_matches_oracle(hip_lib):
