@@ -312,7 +312,7 @@ def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False, force_d
                "config": {"workload": "autoencoder_kl_16x16x16.yaml, %dx%d synthetic crops, z=%dx%dx16, B=%d/GPU, %s%s, %s"
                           % (res, res, lat, lat, batch,
                              "PatchGAN + LPIPS-style loss, optimizers 0 and 1 per batch" if gan else "rec+KL only",
-                             ", activation-checkpointed Decoder" if ckpt else "",
+                             (", Decoder checkpointed by the 'norm' policy" if ckpt == "norm" else ", activation-checkpointed Decoder") if ckpt else "",
                              "bf16 mixed precision" if str(precision) == "bf16" else "fp32")}}
         out.update(diag)
         return out
