@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, BKT == 32 ? 2 : (EPI == EPI_SMB ? 2 : 4)) void
   gemm_body<A_KC, B_KC, EPI, BKT>(p, dsm, blockIdx.x, blockIdx.z);
 }
 
-template <bool A_KC, bool B_KC, int EPI = EPI_NONE, bool OCC3 = (A_KC && B_KC && EPI != EPI_SMB)>
+template <bool A_KC, bool B_KC, int EPI = EPI_NONE, bool OCC3 = (A_KC && B_KC)>
 // OCC3: three blocks per CU (150 registers, the accumulators in VGPRs).  The form with both operands k-contiguous (QK^T-shaped
 // and 1x1-forward products) gains 4-6 % from the third block covering prologue / store bursts, the unsplit batched TN products
 // of the attention backward 3 %; the NN form and the split-K weight-gradient shapes lose 3-10 % with it and stay at two
@@ -471,28 +471,28 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, float* smem, int 
     if (p.flag && __any(bad) && lane == 0) atomicOr(p.flag, 1);
     return;
   }
-  if constexpr (SMB) {   // all loads of the multiplier tile first, then stores only
+  if constexpr (SMB) {   // per 32-row half: all loads of the multiplier tile first, then its stores (one half's 32 values live at a time: the
+                         // kernel fits 168 registers and three blocks share a CU, so that a block's epilogue runs under two others' MFMAs)
     const __amdgpu_buffer_rsrc_t ersrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.emul) + batch * p.sC + (int64_t)m0 * ldc, 0, tile_bytes, 0x00020000);
-    float pv[2][2][16];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned rb_ = row_byte(mt, r);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          pv[mt][nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ersrc, rb_ + colbyte[nt], 0, 0));
-      }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+      float pv[2][16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned rb_ = row_byte(mt, r);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * (alpha * rmv[mt][r]) * pv[mt][nt][r]), crsrc, rb_ + colbyte[nt], 0, 0);
+          pv[nt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ersrc, rb_ + colbyte[nt], 0, 0));
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned rb_ = row_byte(mt, r);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r] * (alpha * rmv[mt][r]) * pv[nt][r]), crsrc, rb_ + colbyte[nt], 0, 0);
+      }
+    }
     return;
   }
 #pragma unroll
