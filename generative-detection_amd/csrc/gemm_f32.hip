@@ -515,6 +515,10 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
     const int batch = (int)(idx / mn);
     const int64_t rem = idx - (int64_t)batch * mn;
     const int row = (int)(rem / p.N), col = (int)(rem - (int64_t)row * p.N);
+#ifdef ODVAE_OLD_REDUCE      // A/B build: one serial chain (the form before round 4's last week)
+    float s_old = 0.f;
+    for (int q = 0; q < p.splits; ++q) s_old += p.partial[((int64_t)q * batches + batch) * mn + rem];
+#endif
     float sk[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains (one chain of `splits` dependent round trips otherwise)
     int sp = 0;
     for (; sp + 3 < p.splits; sp += 4) {
@@ -523,6 +527,9 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int batches) {
     }
     for (; sp < p.splits; ++sp) sk[0] += p.partial[((int64_t)sp * batches + batch) * mn + rem];
     float s = (sk[0] + sk[1]) + (sk[2] + sk[3]);
+#ifdef ODVAE_OLD_REDUCE
+    s = s_old;
+#endif
     s *= p.alpha;
     if (p.bias) s += p.bias[col];
     const int64_t o = batch * p.sC + (int64_t)row * p.ldc + col;

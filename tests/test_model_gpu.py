@@ -5,10 +5,11 @@ Stated fp32 tolerances = at most 4x what the path was MEASURED to use (tools/par
 deviations relative to max|ref|, gradients to max(|ref grad|, 1e-3 * largest gradient)):
   ch=32 @64x64 (no layer wide enough for F(4x4)):  outputs / loss terms 2e-5 (measured 6.7e-6), gradients 4.4e-4 (1.2e-4: a conv bias),
   ch=128 @256x256, Winograd F(4x4,3x3) (default):  outputs / loss terms 8e-5 (1.7e-5), gradients 4.6e-3 (2.8e-5 ... 2.3e-3 between builds
-      that differ ONLY in summation order: the reconstruction term is an L1, its gradient sign(x_rec - x) flips at every pixel whose
-      |x_rec - x| is below the forward's own deviation (1.7e-5 of the value range: a dozen of the 393 216 x 3 values at B = 2), and a
-      flipped pixel moves every decoder gradient behind it -- 9.3e-4 / 6.7e-6 for the decoder, 2.3e-3 / 1.8e-5 for post_quant_conv.weight in
-      two consecutive builds of round 4.  The tolerance covers the unlucky case; profiles/r04_parity_margins.json holds the last run),
+      that differ ONLY in summation order: the reconstruction term is an L1, its gradient sign(x_rec - x) flips at a pixel whose
+      |x_rec - x| is below the forward's own deviation (1.7e-5 of the value range), and ONE flipped value of the 393 216 moves
+      every gradient behind it by 2 / numel of that pixel's Jacobian -- measured with two builds that differ in the split-K reduce's
+      order only (profiles/r04_sign_flip_ab.txt): 1 flipped value -> decoder 9.3e-4, post_quant_conv.weight 2.3e-3; 0 flipped -> 6.7e-6,
+      1.8e-5.  tools/parity_margins.py reports the count (l1_sign_flips).  The tolerance covers two or three flips),
   the same on F(2x2,3x3) (ODVAE_CONV_WINOGRAD4=0):  outputs 2.7e-5 (5.5e-6), gradients 4e-5 (0.9e-5 ... 1.1e-5),
   3-step loss curves 4e-6 (1.3e-6 ... 2.1e-6); weights after 3 Adam steps use 0.08-0.16 of their bound (2.2 lr per step + 5e-3 max|w|)."""
 import os

@@ -16,6 +16,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+if os.environ.get("ODVAE_PROBE_LIB"):      # A/B builds of the library (tools/ab_build.py)
+    from odvae_amd import lib as _ab_lib
+    _ab_lib.LIB_PATH = os.environ["ODVAE_PROBE_LIB"]
+
+
 def rel(a, b):
     a = a.detach().cpu().double(); b = b.detach().cpu().double()
     return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
@@ -45,6 +50,11 @@ def one_step(ch, height, latent_hw, global_step=1, gan=False):
     out["latent_moments"] = rel(post.parameters, aux["posterior"].parameters)
     out["reconstruction"] = rel(dec_obj, aux["dec_obj"])
     out["dec_pose"] = rel(dec_pose, aux["dec_pose"])
+    # pixels where the L1 term's gradient sign(x_hat - x) differs between the two paths (|x_hat - x| below the forward deviation): each
+    # one moves the gradients by a fixed amount, 2 / numel of the reconstruction gradient at that pixel
+    target = model._rescale(batch["patch"].to("cuda:0")).detach().cpu().double()
+    sa, sb = torch.sign(dec_obj.detach().cpu().double() - target), torch.sign(aux["dec_obj"].detach().cpu().double() - target)
+    out["l1_sign_flips"] = {"pixels": int((sa != sb).sum().item()), "of": sa.numel()}
     loss.backward(); loss_ref.backward()
     ref_params = dict(ref.named_parameters())
     scale = max(p.grad.abs().max().item() for p in ref_params.values() if p.grad is not None)
@@ -100,6 +110,10 @@ def main():
     res = {"tolerances_in_the_tests": {"outputs_and_losses": 1e-3, "gradients": 5e-3, "loss_curve": 2e-3,
                                        "weights": "2.2 lr per step + 5e-3 max|w|"},
            "note": "relative deviations HIP vs CPU oracle (parity unpinned: the oracle is this build's restatement); f32 path; B = 2"}
+    if os.environ.get("ODVAE_MARGINS_ONLY") == "ch128":      # one comparison only (for A/B builds): the benchmark's network, F(4x4), step 1
+        ops.WINOGRAD4 = True
+        print(json.dumps(one_step(None, 256, 16, 1), indent=1), flush=True)
+        return
     for f4 in (True, False):
         ops.WINOGRAD4 = f4
         tag = "F(4x4,3x3)" if f4 else "F(2x2,3x3)"
