@@ -1,11 +1,19 @@
 // First form of DESIGN.md §7's next kernel: the stride-1 3x3 weight gradient in the F(4x4,3x3) domain (the arithmetic: tools/wgrad_wino4_math.py).
-// NOT part of the library (written in the last GPU minutes of round 4; 206 VGPRs, no spills, 2 waves per SIMD): a standalone program that
+// NOT part of the library (written in the last GPU minutes of round 4): a standalone program that
 // checks itself against a CPU loop (ragged H, W; passes at 3.0e-6 of max|dW|) and times the 128 -> 128 @256^2 layer (profiles/r04_wgrad_wino4_probe.txt).
+// 256 VGPRs, one spilled register in this form.
 //   dW[co][ci] = Aw^T [ sum_tiles (Gw dy Gw^T) .* (B^T x B) ] Aw       per 4x4 output tile, 36 products instead of 144
 // Blocking (the forward kernel's, as sized in DESIGN.md): a block owns all 36 xi x 64 co x 32 ci of the transform-domain sum (8 waves: wave =
 // (xi group of 9, co half of 32), nine 32 x 32 accumulators = 144 registers) over a contiguous range of tiles, 8 tiles per chunk:
-//   per chunk every thread transforms one (tile, co) pair of dy (4x4 -> 6x6) and threads 0..255 one (tile, ci) pair of x (6x6 -> 6x6),
-//   U [36][8][64] and V [36][8][32] go to LDS (110.6 KB), then 4 k-steps x 9 xi of v_mfma_f32_32x32x2_f32 per wave (k = tile).
+//   stages of 4 tiles; in LDS two stages of U [36][4][64] and two 8-tile stages of V [36][8][32] (147.5 KB); waves 0-3 transform dy (4x4 -> 6x6,
+//   one (tile, co) pair per thread and stage), waves 4-7 x (6x6 -> 6x6, one (tile, ci) pair per thread every second stage), every wave
+//   multiplies: 2 k-steps x 9 xi of v_mfma_f32_32x32x2_f32 per stage (k = tile).
+//   History (B = 8, 128 -> 128 @256^2, 32 splits): one 8-tile stage, fetch-transform-multiply in sequence 0.933 ms; operands of the next chunk
+//   fetched before the MFMAs 0.771 ms (the best so far: 200 TFLOP/s direct-equivalent, the rate of the library's F(2x2)-domain kernel); two 4-tile
+//   stages with x on waves 4-5 only 0.921 ms (two SIMDs carry 37 % more vector work); this form 0.827 ms -- putting one wave of a SIMD in the
+//   transforms while the other multiplies did NOT overlap the two (as tools/mfma_valu_coexec_probe.hip found for bf16), so what is left is to
+//   shorten the vector work itself: the two integer divisions per fetch (tile -> n, ty, tx), one v_cndmask per load, and the finish kernel
+//   (64 blocks reading 75 MB: ~0.1 ms of every number above; 64 / 128 splits cost +0.21 / +0.72 ms through it).
 // Grid = (Cout / 64) x (Cin / 32) x splits; a second kernel sums the splits and applies Aw^T . Aw.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/wgrad_wino4_probe.hip -o tools/bin/wgrad_wino4 ; run on the GPU box: tools/bin/wgrad_wino4
 #include <hip/hip_runtime.h>
@@ -20,8 +28,9 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 }
 constexpr unsigned OOB = 0xFFFFFFF0u;      // the host checks that both operands are smaller than this
 
-constexpr int CO_B = 64, CI_B = 32, TCH = 8, NXI = 36;
-constexpr int LDS_U = NXI * TCH * CO_B, LDS_V = NXI * TCH * CI_B;      // floats
+constexpr int CO_B = 64, CI_B = 32, TS = 4, TCH = 8, NXI = 36;      // TS tiles per LDS stage, two stages; a split is a multiple of TCH tiles
+constexpr int TV = 2 * TS;      // x is staged 8 tiles at a time (one pair per thread of waves 4-7 every second stage)
+constexpr int LDS_U = 2 * NXI * TS * CO_B, LDS_V = 2 * NXI * TV * CI_B;      // floats
 
 struct Params {
   const float* x;       // [N][H][W][Cin]
@@ -67,8 +76,6 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int tbeg = split * p.tiles_per_split, tend = tbeg + p.tiles_per_split;      // tiles_per_split is a multiple of TCH
-  const int ut = tid >> 6, uco = tid & 63;          // this thread's (tile, co) of the dy transform
-  const int vt = (tid >> 5) & 7, vci = tid & 31;    // and (tile, ci) of the x transform (threads 0..255)
   const int per_img = p.TY * p.TX;
   // x: the descriptor starts one row and one pixel BEFORE the tensor, so that the offset of a patch's first (halo) element is never negative:
   // the hardware's range check looks at the vector offset alone, a wrapped one reads as out of range even when offset + soffset is inside
@@ -78,81 +85,111 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
                                                                       (int)(unsigned)((int64_t)p.N * p.H * p.W * p.Cin * 4 + xlead), 0x00020000);
   const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)(unsigned)((int64_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
 
-  for (int t0 = tbeg; t0 < tend; t0 += TCH) {
-    {      // U = Gw dy Gw^T
-      const int t = t0 + ut;
-      const bool live = t < p.tiles;
-      const int tc = live ? t : 0;
-      const int n = tc / per_img, r = tc - n * per_img, ty = r / p.TX, tx = r - ty * p.TX;
-      float d[4][4];
-      const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cout + co0 + uco) * 4);
-      unsigned colbase[4];      // per column: the tile's first row, or out of range; the row's part of the offset is wave-uniform (soffset)
+  // Stages of TS = 4 tiles, two of them in LDS.  Waves 0-3 transform dy (one (tile, co) pair per thread), waves 4-5 transform x (one
+  // (tile, ci) pair per thread); in every iteration waves 0-3 transform stage s + 1 FIRST and multiply stage s AFTER, waves 4-7 the other
+  // way round, so that each SIMD (waves w and w + 4) has one wave in vector work while the other is in the matrix pipe.  The operands of
+  // stage s + 2 are fetched into registers right after stage s + 1 left them.
+  const bool is_u = wave < 4;
+  const int ut = wave & 3, uco = lane;                         // waves 0-3: tile of the 4-tile stage, co
+  const int vt = ((tid >> 5) & 7), vci = tid & 31;             // waves 4-7: tile of the 8-tile x stage, ci
+  float d[4][4], xv[6][6];
+  auto fetch_u = [&](int t0) {
+    const int t = t0 + ut;
+    const bool live = t < p.tiles;
+    const int tc = live ? t : 0;
+    const int n = tc / per_img, r = tc - n * per_img, ty = r / p.TX, tx = r - ty * p.TX;
+    const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cout + co0 + uco) * 4);
+    unsigned colbase[4];      // per column: the tile's first row, or out of range; the row's part of the offset is wave-uniform (soffset)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) colbase[b] = (live && 4 * tx + b < p.W) ? base + (unsigned)(b * p.Cout * 4) : OOB;
+    for (int b = 0; b < 4; ++b) colbase[b] = (live && 4 * tx + b < p.W) ? base + (unsigned)(b * p.Cout * 4) : OOB;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const bool rowok = 4 * ty + a < p.H;
+    for (int a = 0; a < 4; ++a) {
+      const bool rowok = 4 * ty + a < p.H;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) d[a][b] = bload(dyrs, rowok ? colbase[b] : OOB, a * p.W * p.Cout * 4);
-      }
-      float tt[6][4];      // Gw dy: columns
+      for (int b = 0; b < 4; ++b) d[a][b] = bload(dyrs, rowok ? colbase[b] : OOB, a * p.W * p.Cout * 4);
+    }
+  };
+  auto fetch_v = [&](int t0) {      // the 6 x 6 patch with its 1-pixel zero halo
+    const int t = t0 + vt;
+    const bool live = t < p.tiles;
+    const int tc = live ? t : 0;
+    const int n = tc / per_img, r = tc - n * per_img, ty = r / p.TX, tx = r - ty * p.TX;
+    const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cin + ci0 + vci) * 4);      // of element (-1, -1) of the patch, relative to the shifted descriptor
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float in[4] = {d[0][b], d[1][b], d[2][b], d[3][b]};
-        float o[6];
-        gw6(in, o);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
-      }
+    for (int b = 0; b < 6; ++b) {
+      const int xx = 4 * tx - 1 + b;
+      const unsigned colbase = (live && xx >= 0 && xx < p.W) ? base + (unsigned)(b * p.Cin * 4) : OOB;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        float o[6];
-        gw6(tt[a], o);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) U[((a * 6 + b) * TCH + ut) * CO_B + uco] = o[b];
+        const bool rowok = 4 * ty - 1 + a >= 0 && 4 * ty - 1 + a < p.H;
+        xv[a][b] = bload(xrs, rowok ? colbase : OOB, a * p.W * p.Cin * 4);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);      // keep the two transforms' registers apart (23 spilled registers otherwise)
-    if (tid < 256) {      // V = B^T x B (1-pixel zero halo)
-      const int t = t0 + vt;
-      const bool live = t < p.tiles;
-      const int tc = live ? t : 0;
-      const int n = tc / per_img, r = tc - n * per_img, ty = r / p.TX, tx = r - ty * p.TX;
-      float tt[6][6];
-      const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cin + ci0 + vci) * 4);      // of element (-1, -1) of the patch, relative to the shifted descriptor
-      bool rowok[6];
+  };
+  auto transform_u = [&](int st) {      // U = Gw dy Gw^T
+    float tt[6][4];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) rowok[a] = 4 * ty - 1 + a >= 0 && 4 * ty - 1 + a < p.H;
+    for (int b = 0; b < 4; ++b) {
+      const float in[4] = {d[0][b], d[1][b], d[2][b], d[3][b]};
+      float o[6];
+      gw6(in, o);
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {      // a column of the patch at a time: six loads, one line transform
-        const int xx = 4 * tx - 1 + b;
-        const unsigned colbase = (live && xx >= 0 && xx < p.W) ? base + (unsigned)(b * p.Cin * 4) : OOB;
-        float in[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) in[a] = bload(xrs, rowok[a] ? colbase : OOB, a * p.W * p.Cin * 4);
-        float o[6];
-        bt6(in, o);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
-      }
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        float o[6];
-        bt6(tt[a], o);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) V[((a * 6 + b) * TCH + vt) * CI_B + vci] = o[b];
-      }
+      for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
     }
-    __syncthreads();
-#pragma unroll 2
-    for (int ks = 0; ks < TCH / 2; ++ks) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float o[6];
+      gw6(tt[a], o);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) U[(((st * NXI) + a * 6 + b) * TS + ut) * CO_B + uco] = o[b];
+    }
+  };
+  auto transform_v = [&](int st) {      // V = B^T x B
+    float tt[6][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const float in[6] = {xv[0][b], xv[1][b], xv[2][b], xv[3][b], xv[4][b], xv[5][b]};
+      float o[6];
+      bt6(in, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float o[6];
+      bt6(tt[a], o);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) V[(((st * NXI) + a * 6 + b) * TV + vt) * CI_B + vci] = o[b];
+    }
+  };
+  auto multiply = [&](int s) {      // stage s of the split: U parity s & 1; V parity (s >> 1) & 1, its tiles 4 (s & 1) ..
+    const int su = s & 1, sv = (s >> 1) & 1, tv0 = TS * (s & 1);
+#pragma unroll
+    for (int ks = 0; ks < TS / 2; ++ks) {
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
         const int xi = 9 * g + j;
-        const float a = U[(xi * TCH + 2 * ks + hk) * CO_B + 32 * hco + li];      // A: row = co, k = tile
-        const float b = V[(xi * TCH + 2 * ks + hk) * CI_B + li];                 // B: k = tile, column = ci
+        const float a = U[((su * NXI + xi) * TS + 2 * ks + hk) * CO_B + 32 * hco + li];      // A: row = co, k = tile
+        const float b = V[((sv * NXI + xi) * TV + tv0 + 2 * ks + hk) * CI_B + li];           // B: k = tile, column = ci
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
       }
+    }
+  };
+
+  // Stages past the split's end are transformed into the LDS stage nobody multiplies (tiles past the tensor's end fetch zeros).
+  if (is_u) { fetch_u(tbeg); transform_u(0); fetch_u(tbeg + TS); }
+  else      { fetch_v(tbeg); transform_v(0); fetch_v(tbeg + TV); }
+  __syncthreads();
+  const int stages = p.tiles_per_split / TS;      // even (a split is a multiple of 8 tiles)
+  for (int s = 0; s < stages; ++s) {
+    const int t0 = tbeg + s * TS;
+    if (is_u) {
+      transform_u((s + 1) & 1);
+      fetch_u(t0 + 2 * TS);
+      multiply(s);
+    } else {
+      multiply(s);
+      if (s & 1) { transform_v(((s >> 1) + 1) & 1); fetch_v(t0 - TS + 2 * TV); }
     }
     __syncthreads();
   }
