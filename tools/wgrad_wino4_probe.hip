@@ -1,21 +1,29 @@
-// First form of DESIGN.md §7's next kernel: the stride-1 3x3 weight gradient in the F(4x4,3x3) domain (the arithmetic: tools/wgrad_wino4_math.py).
-// NOT part of the library (written in the last GPU minutes of round 4): a standalone program that
-// checks itself against a CPU loop (ragged H, W; passes at 3.0e-6 of max|dW|) and times the 128 -> 128 @256^2 layer (profiles/r04_wgrad_wino4_probe.txt).
-// 256 VGPRs, one spilled register in this form.
+// DESIGN.md §7's next kernel in a first form: the stride-1 3x3 weight gradient in the F(4x4,3x3) domain (the arithmetic: tools/wgrad_wino4_math.py).
+// NOT part of the library (written and run in the last GPU minutes of round 4): a standalone program that checks itself against a CPU loop
+// (ragged H, W) and times the 128 -> 128 @256^2 layer; results in profiles/r04_wgrad_wino4_probe.txt.
 //   dW[co][ci] = Aw^T [ sum_tiles (Gw dy Gw^T) .* (B^T x B) ] Aw       per 4x4 output tile, 36 products instead of 144
 // Blocking (the forward kernel's, as sized in DESIGN.md): a block owns all 36 xi x 64 co x 32 ci of the transform-domain sum (8 waves: wave =
 // (xi group of 9, co half of 32), nine 32 x 32 accumulators = 144 registers) over a contiguous range of tiles, 8 tiles per chunk:
-//   stages of 4 tiles; in LDS two stages of U [36][4][64] and two 8-tile stages of V [36][8][32] (147.5 KB); waves 0-3 transform dy (4x4 -> 6x6,
-//   one (tile, co) pair per thread and stage), waves 4-7 x (6x6 -> 6x6, one (tile, ci) pair per thread every second stage), every wave
-//   multiplies: 2 k-steps x 9 xi of v_mfma_f32_32x32x2_f32 per stage (k = tile).
-//   History (B = 8, 128 -> 128 @256^2, 32 splits): one 8-tile stage, fetch-transform-multiply in sequence 0.933 ms; operands of the next chunk
-//   fetched before the MFMAs 0.771 ms (the best so far: 200 TFLOP/s direct-equivalent, the rate of the library's F(2x2)-domain kernel); two 4-tile
-//   stages with x on waves 4-5 only 0.921 ms (two SIMDs carry 37 % more vector work); this form 0.827 ms -- putting one wave of a SIMD in the
-//   transforms while the other multiplies did NOT overlap the two (as tools/mfma_valu_coexec_probe.hip found for bf16), so what is left is to
-//   shorten the vector work itself: the two integer divisions per fetch (tile -> n, ty, tx), one v_cndmask per load, and the finish kernel
-//   (64 blocks reading 75 MB: ~0.1 ms of every number above; 64 / 128 splits cost +0.21 / +0.72 ms through it).
+//   every thread transforms one (tile, co) pair of dy (4x4 -> 6x6) and threads 0..255 one (tile, ci) pair of x (6x6 -> 6x6) per chunk,
+//   U [36][8][64] and V [36][8][32] go to LDS (110.6 KB), then 4 k-steps x 9 xi of v_mfma_f32_32x32x2_f32 per wave (k = tile); the next
+//   chunk's operands are fetched into registers before the MFMAs.  255 VGPRs, no spills, 2 waves per SIMD.
 // Grid = (Cout / 64) x (Cin / 32) x splits; a second kernel sums the splits and applies Aw^T . Aw.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/wgrad_wino4_probe.hip -o tools/bin/wgrad_wino4 ; run on the GPU box: tools/bin/wgrad_wino4
+// Measured (B = 8, 128 -> 128 @256^2, 32 splits; check 3.0e-6 of max|dW| in every form):
+//   fetch -> transform -> multiply in sequence                          0.933 ms
+//   THIS FORM (operands of the next chunk fetched before the MFMAs)      0.771 ms = 200 TFLOP/s direct-equivalent, the rate of the library's
+//                                                                        F(2x2)-domain kernel (204)
+//   two 4-tile LDS stages, waves 0-3 dy / waves 4-5 x, the two waves of a SIMD in opposite phases (one transforms while the other
+//   multiplies)                                                          0.921 ms (two SIMDs carry 37 % more vector work)
+//   the same with x staged 8 tiles over waves 4-7 (balanced; 147.5 KB)   0.827 ms (git show e75c537:tools/wgrad_wino4_probe.hip)
+// The opposite-phase forms did NOT overlap matrix and vector work (as tools/mfma_valu_coexec_probe.hip found for bf16): the bound is the sum of
+// the two, and the way on is less vector work.  -DWGW4_NEXT=1 builds the two next steps, written after the GPU minutes ran out and NOT YET
+// RUN (the program's own check will tell): the tile -> (n, ty, tx) decode by a float reciprocal with a one-step correction instead of two
+// integer divisions per fetch (~100 of ~650 vector instructions per chunk on waves 0-3), and the sum over splits by 36 Cout Cin / 256 blocks
+// instead of Cout Cin / 256 (the finish kernel is ~0.1 ms of the numbers above; 64 / 128 splits cost +0.21 / +0.72 ms through it).
+// Build: hipcc --offload-arch=gfx950 -O3 [-DWGW4_NEXT=1] tools/wgrad_wino4_probe.hip -o tools/bin/wgrad_wino4 ; run on the GPU box: tools/bin/wgrad_wino4
+#ifndef WGW4_NEXT
+#define WGW4_NEXT 0
+#endif
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -28,15 +36,15 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 }
 constexpr unsigned OOB = 0xFFFFFFF0u;      // the host checks that both operands are smaller than this
 
-constexpr int CO_B = 64, CI_B = 32, TS = 4, TCH = 8, NXI = 36;      // TS tiles per LDS stage, two stages; a split is a multiple of TCH tiles
-constexpr int TV = 2 * TS;      // x is staged 8 tiles at a time (one pair per thread of waves 4-7 every second stage)
-constexpr int LDS_U = 2 * NXI * TS * CO_B, LDS_V = 2 * NXI * TV * CI_B;      // floats
+constexpr int CO_B = 64, CI_B = 32, TCH = 8, NXI = 36;
+constexpr int LDS_U = NXI * TCH * CO_B, LDS_V = NXI * TCH * CI_B;      // floats
 
 struct Params {
   const float* x;       // [N][H][W][Cin]
   const float* dy;      // [N][H][W][Cout]
   float* partial;       // [splits][36][Cout][Cin]
   int N, H, W, Cin, Cout, TY, TX, tiles, tiles_per_split;
+  float inv_per_img, inv_tx;      // WGW4_NEXT: reciprocals for the tile decode (tiles < 2^24, host-checked)
 };
 
 // B^T d for one line of six (the forward kernel's input transform)
@@ -60,6 +68,28 @@ __device__ __forceinline__ void gw6(const float g[4], float o[6]) {
   o[5] = g[3];
 }
 
+// tile index -> image, tile row, tile column
+__device__ __forceinline__ void decode_tile(const Params& p, int t, int& n, int& ty, int& tx) {
+  const int per_img = p.TY * p.TX;
+#if WGW4_NEXT
+  // t < 2^24 is exact in a float and the rounded product is off by at most one: one correction step each way
+  int q = (int)((float)t * p.inv_per_img);
+  int r = t - q * per_img;
+  if (r < 0) { --q; r += per_img; }
+  if (r >= per_img) { ++q; r -= per_img; }
+  int q2 = (int)((float)r * p.inv_tx);
+  int r2 = r - q2 * p.TX;
+  if (r2 < 0) { --q2; r2 += p.TX; }
+  if (r2 >= p.TX) { ++q2; r2 -= p.TX; }
+  n = q; ty = q2; tx = r2;
+#else
+  n = t / per_img;
+  const int r = t - n * per_img;
+  ty = r / p.TX;
+  tx = r - ty * p.TX;
+#endif
+}
+
 __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
   extern __shared__ float smem[];
   float* U = smem;                 // [xi][tile][co]
@@ -76,7 +106,8 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int tbeg = split * p.tiles_per_split, tend = tbeg + p.tiles_per_split;      // tiles_per_split is a multiple of TCH
-  const int per_img = p.TY * p.TX;
+  const int ut = tid >> 6, uco = tid & 63;          // this thread's (tile, co) of the dy transform
+  const int vt = (tid >> 5) & 7, vci = tid & 31;    // and (tile, ci) of the x transform (threads 0..255)
   // x: the descriptor starts one row and one pixel BEFORE the tensor, so that the offset of a patch's first (halo) element is never negative:
   // the hardware's range check looks at the vector offset alone, a wrapped one reads as out of range even when offset + soffset is inside
   // (the first run of this program: every tile of the first tile row came back zero).  Halo elements are never fetched (OOB offset).
@@ -85,111 +116,99 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
                                                                       (int)(unsigned)((int64_t)p.N * p.H * p.W * p.Cin * 4 + xlead), 0x00020000);
   const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)(unsigned)((int64_t)p.N * p.H * p.W * p.Cout * 4), 0x00020000);
 
-  // Stages of TS = 4 tiles, two of them in LDS.  Waves 0-3 transform dy (one (tile, co) pair per thread), waves 4-5 transform x (one
-  // (tile, ci) pair per thread); in every iteration waves 0-3 transform stage s + 1 FIRST and multiply stage s AFTER, waves 4-7 the other
-  // way round, so that each SIMD (waves w and w + 4) has one wave in vector work while the other is in the matrix pipe.  The operands of
-  // stage s + 2 are fetched into registers right after stage s + 1 left them.
-  const bool is_u = wave < 4;
-  const int ut = wave & 3, uco = lane;                         // waves 0-3: tile of the 4-tile stage, co
-  const int vt = ((tid >> 5) & 7), vci = tid & 31;             // waves 4-7: tile of the 8-tile x stage, ci
+  // The operands of chunk c + 1 are fetched into registers before the MFMAs of chunk c and transformed after them (one LDS stage: the
+  // fetch latency hides behind the matrix work, the transforms do not).
   float d[4][4], xv[6][6];
-  auto fetch_u = [&](int t0) {
-    const int t = t0 + ut;
-    const bool live = t < p.tiles;
-    const int tc = live ? t : 0;
-    const int n = tc / per_img, r = tc - n * per_img, ty = r / p.TX, tx = r - ty * p.TX;
-    const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cout + co0 + uco) * 4);
-    unsigned colbase[4];      // per column: the tile's first row, or out of range; the row's part of the offset is wave-uniform (soffset)
+  auto fetch = [&](int t0) {
+    {
+      const int t = t0 + ut;
+      const bool live = t < p.tiles;
+      const int tc = live ? t : 0;
+      int n, ty, tx;
+      decode_tile(p, tc, n, ty, tx);
+      const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cout + co0 + uco) * 4);
+      unsigned colbase[4];      // per column: the tile's first row, or out of range; the row's part of the offset is wave-uniform (soffset)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) colbase[b] = (live && 4 * tx + b < p.W) ? base + (unsigned)(b * p.Cout * 4) : OOB;
+      for (int b = 0; b < 4; ++b) colbase[b] = (live && 4 * tx + b < p.W) ? base + (unsigned)(b * p.Cout * 4) : OOB;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const bool rowok = 4 * ty + a < p.H;
+      for (int a = 0; a < 4; ++a) {
+        const bool rowok = 4 * ty + a < p.H;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) d[a][b] = bload(dyrs, rowok ? colbase[b] : OOB, a * p.W * p.Cout * 4);
+        for (int b = 0; b < 4; ++b) d[a][b] = bload(dyrs, rowok ? colbase[b] : OOB, a * p.W * p.Cout * 4);
+      }
     }
-  };
-  auto fetch_v = [&](int t0) {      // the 6 x 6 patch with its 1-pixel zero halo
-    const int t = t0 + vt;
-    const bool live = t < p.tiles;
-    const int tc = live ? t : 0;
-    const int n = tc / per_img, r = tc - n * per_img, ty = r / p.TX, tx = r - ty * p.TX;
-    const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cin + ci0 + vci) * 4);      // of element (-1, -1) of the patch, relative to the shifted descriptor
+    if (tid < 256) {      // the 6 x 6 patch with its 1-pixel zero halo
+      const int t = t0 + vt;
+      const bool live = t < p.tiles;
+      const int tc = live ? t : 0;
+      int n, ty, tx;
+      decode_tile(p, tc, n, ty, tx);
+      const unsigned base = (unsigned)((((n * p.H + 4 * ty) * p.W + 4 * tx) * p.Cin + ci0 + vci) * 4);      // of element (-1, -1) of the patch, relative to the shifted descriptor
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const int xx = 4 * tx - 1 + b;
-      const unsigned colbase = (live && xx >= 0 && xx < p.W) ? base + (unsigned)(b * p.Cin * 4) : OOB;
+      for (int b = 0; b < 6; ++b) {
+        const int xx = 4 * tx - 1 + b;
+        const unsigned colbase = (live && xx >= 0 && xx < p.W) ? base + (unsigned)(b * p.Cin * 4) : OOB;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const bool rowok = 4 * ty - 1 + a >= 0 && 4 * ty - 1 + a < p.H;
-        xv[a][b] = bload(xrs, rowok ? colbase : OOB, a * p.W * p.Cin * 4);
+        for (int a = 0; a < 6; ++a) {
+          const bool rowok = 4 * ty - 1 + a >= 0 && 4 * ty - 1 + a < p.H;
+          xv[a][b] = bload(xrs, rowok ? colbase : OOB, a * p.W * p.Cin * 4);
+        }
       }
     }
   };
-  auto transform_u = [&](int st) {      // U = Gw dy Gw^T
-    float tt[6][4];
+  auto transform = [&]() {
+    {      // U = Gw dy Gw^T
+      float tt[6][4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float in[4] = {d[0][b], d[1][b], d[2][b], d[3][b]};
-      float o[6];
-      gw6(in, o);
+      for (int b = 0; b < 4; ++b) {
+        const float in[4] = {d[0][b], d[1][b], d[2][b], d[3][b]};
+        float o[6];
+        gw6(in, o);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
+        for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        float o[6];
+        gw6(tt[a], o);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) U[((a * 6 + b) * TCH + ut) * CO_B + uco] = o[b];
+      }
     }
+    if (tid < 256) {      // V = B^T x B
+      float tt[6][6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      float o[6];
-      gw6(tt[a], o);
+      for (int b = 0; b < 6; ++b) {
+        const float in[6] = {xv[0][b], xv[1][b], xv[2][b], xv[3][b], xv[4][b], xv[5][b]};
+        float o[6];
+        bt6(in, o);
 #pragma unroll
-      for (int b = 0; b < 6; ++b) U[(((st * NXI) + a * 6 + b) * TS + ut) * CO_B + uco] = o[b];
-    }
-  };
-  auto transform_v = [&](int st) {      // V = B^T x B
-    float tt[6][6];
+        for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
+      }
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const float in[6] = {xv[0][b], xv[1][b], xv[2][b], xv[3][b], xv[4][b], xv[5][b]};
-      float o[6];
-      bt6(in, o);
+      for (int a = 0; a < 6; ++a) {
+        float o[6];
+        bt6(tt[a], o);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) tt[a][b] = o[a];
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      float o[6];
-      bt6(tt[a], o);
-#pragma unroll
-      for (int b = 0; b < 6; ++b) V[(((st * NXI) + a * 6 + b) * TV + vt) * CI_B + vci] = o[b];
-    }
-  };
-  auto multiply = [&](int s) {      // stage s of the split: U parity s & 1; V parity (s >> 1) & 1, its tiles 4 (s & 1) ..
-    const int su = s & 1, sv = (s >> 1) & 1, tv0 = TS * (s & 1);
-#pragma unroll
-    for (int ks = 0; ks < TS / 2; ++ks) {
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const int xi = 9 * g + j;
-        const float a = U[((su * NXI + xi) * TS + 2 * ks + hk) * CO_B + 32 * hco + li];      // A: row = co, k = tile
-        const float b = V[((sv * NXI + xi) * TV + tv0 + 2 * ks + hk) * CI_B + li];           // B: k = tile, column = ci
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        for (int b = 0; b < 6; ++b) V[((a * 6 + b) * TCH + vt) * CI_B + vci] = o[b];
       }
     }
   };
 
-  // Stages past the split's end are transformed into the LDS stage nobody multiplies (tiles past the tensor's end fetch zeros).
-  if (is_u) { fetch_u(tbeg); transform_u(0); fetch_u(tbeg + TS); }
-  else      { fetch_v(tbeg); transform_v(0); fetch_v(tbeg + TV); }
-  __syncthreads();
-  const int stages = p.tiles_per_split / TS;      // even (a split is a multiple of 8 tiles)
-  for (int s = 0; s < stages; ++s) {
-    const int t0 = tbeg + s * TS;
-    if (is_u) {
-      transform_u((s + 1) & 1);
-      fetch_u(t0 + 2 * TS);
-      multiply(s);
-    } else {
-      multiply(s);
-      if (s & 1) { transform_v(((s >> 1) + 1) & 1); fetch_v(t0 - TS + 2 * TV); }
+  fetch(tbeg);
+  for (int t0 = tbeg; t0 < tend; t0 += TCH) {
+    transform();
+    __syncthreads();
+    if (t0 + TCH < tend) fetch(t0 + TCH);
+#pragma unroll 2
+    for (int ks = 0; ks < TCH / 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int xi = 9 * g + j;
+        const float a = U[(xi * TCH + 2 * ks + hk) * CO_B + 32 * hco + li];      // A: row = co, k = tile
+        const float b = V[(xi * TCH + 2 * ks + hk) * CI_B + li];                 // B: k = tile, column = ci
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -204,6 +223,19 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
       out[(int64_t)row * p.Cin] = acc[j][r];
     }
   }
+}
+
+// WGW4_NEXT: the sum over splits on its own, one thread per (xi, co, ci), into split 0's slab (every thread reads and writes its own element only)
+__global__ void wgrad_wino4_sum_kernel(float* partial, int splits, int64_t n36) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n36) return;
+  float sk[4] = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 3 < splits; s += 4)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sk[j] += partial[(int64_t)(s + j) * n36 + idx];
+  for (; s < splits; ++s) sk[0] += partial[(int64_t)s * n36 + idx];
+  partial[idx] = (sk[0] + sk[1]) + (sk[2] + sk[3]);
 }
 
 // dW[co][ci][3][3] = Aw^T (sum over splits of M[.][co][ci]) Aw,  Aw^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1]
@@ -243,6 +275,8 @@ static Run run(int N, int H, int W, int Cin, int Cout, int splits_want, const st
   Params p{};
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.TY = (H + 3) / 4; p.TX = (W + 3) / 4; p.tiles = N * p.TY * p.TX;
+  p.inv_per_img = 1.0f / (float)(p.TY * p.TX); p.inv_tx = 1.0f / (float)p.TX;
+  if (p.tiles >= (1 << 24) - 64) { fprintf(stderr, "tile count %d too large for the float decode\n", p.tiles); exit(1); }
   int splits = splits_want;
   while (splits > 1 && (p.tiles + splits - 1) / splits < TCH) splits /= 2;
   p.tiles_per_split = (((p.tiles + splits - 1) / splits) + TCH - 1) / TCH * TCH;
@@ -259,7 +293,13 @@ static Run run(int N, int H, int W, int Cin, int Cout, int splits_want, const st
   for (int it = 0; it < reps + 1; ++it) {
     if (it == 1) HIP_OK(hipEventRecord(e0));
     hipLaunchKernelGGL(wgrad_wino4_kernel, dim3(Cout / CO_B, Cin / CI_B, splits), dim3(512), lds, 0, p);
+#if WGW4_NEXT
+    const int64_t n36 = (int64_t)NXI * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_wino4_sum_kernel, dim3((unsigned)((n36 + 255) / 256)), dim3(256), 0, 0, dpart, splits, n36);
+    hipLaunchKernelGGL(wgrad_wino4_finish_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, 0, dpart, 1, Cout, Cin, ddw);
+#else
     hipLaunchKernelGGL(wgrad_wino4_finish_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, 0, dpart, splits, Cout, Cin, ddw);
+#endif
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
