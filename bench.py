@@ -36,6 +36,98 @@ PEAK_HBM_GBS = 8000.0          # HBM3E
 ALGORITHMIC_GFLOP_PER_IMAGE = {256: 1449.9, 512: 8901.6, 64: 75.5}   # fwd + bwd, VAE only
 
 
+LINE_LIMIT = 4000   # bytes of the ONE stdout line: the driver parses it from a bounded tail (round 4's 22.6 KB line was not parsed)
+
+
+def _r(v, sig=6):
+    """Strict-JSON number: 6 significant digits, no NaN / Infinity (those become null)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_record(full, detail_path=None):
+    """The ONE line for stdout, from the full record: the contract's keys, `roofline` (dominant kernel), `roofline_step`,
+    `cpu_baseline`, and per side run only {value, ms_per_step, steps, dtype}.  Everything else (per-step arrays, sysfs states, GC,
+    cgroup, allocator, kernel variants, the other kernel families) stays in the full record, written to `detail_path`."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "ranks_joined", "backend", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "vs_baseline", "dtype", "data", "selftest", "ranks_in_lockstep"))
+    if "config" in full:
+        out["config"] = full["config"]
+    for k in ("host_enqueue_ms_per_step", "gpu_elapsed_ms_per_step", "peak_device_memory_gb"):
+        if full.get(k) is not None:
+            out[k] = _r(full[k], 5)
+    if isinstance(full.get("gpu_step_ms"), dict):
+        out["gpu_step_ms_median"] = _r(full["gpu_step_ms"].get("median"), 5)
+    if isinstance(full.get("roofline"), dict):
+        out["roofline"] = _pick(full["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                   "algorithmic_gflop_per_launch", "issued_gflop_per_launch", "algorithmic_tflops", "kernel",
+                                                   "launches", "sampled_1_in", "avg_launch_ms", "share_of_step_time"))
+    if isinstance(full.get("roofline_step"), dict):
+        out["roofline_step"] = _pick(full["roofline_step"], ("bound", "achieved", "peak", "unit", "frac", "issued_tflop_per_step",
+                                                             "algorithmic_tflop_per_step"))
+    if isinstance(full.get("roofline_others"), list):    # one short row per further kernel family: [name, bound, frac, share of the step]
+        out["roofline_others"] = [[str(e.get("kernel", "")).split(" ")[0], e.get("bound"), _r(e.get("frac"), 3), _r(e.get("share_of_step_time"), 3)]
+                                  for e in full["roofline_others"]]
+    if isinstance(full.get("cpu_baseline"), dict):
+        out["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+        if isinstance(full["cpu_baseline"].get("config1"), dict):
+            out["cpu_baseline"]["config1"] = _pick(full["cpu_baseline"]["config1"], ("value", "cores", "sample"))
+    if isinstance(full.get("other_configs"), dict):
+        oc = {}
+        for k, v in full["other_configs"].items():
+            key = v.get("short", k) if isinstance(v, dict) else k
+            oc[key] = ({"error": str(v.get("error"))[:120]} if isinstance(v, dict) and "error" in v
+                       else _pick(v, ("value", "ms_per_step", "steps", "dtype")))
+        out["other_configs"] = oc
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    for drop in ("roofline_others", "other_configs", "gpu_step_ms_median", "peak_device_memory_gb", "host_enqueue_ms_per_step"):
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(drop, None)     # never the contract keys, `roofline` or `cpu_baseline`
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def _json_safe(o):
+    """The full record as strict JSON too (NaN / Infinity -> null)."""
+    if isinstance(o, dict):
+        return {str(k): _json_safe(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_json_safe(v) for v in o]
+    if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+        return None
+    return o
+
+
+def emit(full, json_fd):
+    """Full record -> bench_detail.json beside this script (and a copy under gpurun_out/ when that directory exists, so a gpurun call
+    brings it home) and stderr stays free of it; the compact line -> the saved stdout descriptor."""
+    rel = None
+    full = _json_safe(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(full, f, indent=1, allow_nan=False)
+                rel = rel or os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT)
+            except OSError as e:
+                sys.stderr.write("[bench] could not write the detail record in %s: %s\n" % (d, e))
+    line = compact_record(full, rel)
+    os.write(json_fd, (line + "\n").encode())
+    return line
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,7 +483,7 @@ def launcher_selftest(args, json_fd):
         out = {"metric": "launcher self-test (gloo, host tensors; NOT a benchmark)", "value": 4 * world * args.steps / t.item(),
                "unit": "samples/s", "n_gpus": world, "ranks_joined": int(joined.item()), "backend": "gloo",
                "steps": args.steps, "warmup": 0, "ranks_in_lockstep": bool(lo.item() == hi.item()), "selftest": True}
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd)
     dist.destroy_process_group()
 
 
@@ -644,18 +736,18 @@ def main():
             # order: the bf16 run at the headline shape goes FIRST (fresh allocator, nothing bf16 has run yet) and is repeated LAST,
             # after the 512x512 run and the GAN run, so the record itself shows whether its rate depends on what ran before it
             oc = {}
-            oc["configs[1] shape (256x256, B=32) in bf16 mixed precision"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
-            oc["configs[4] 512x512 z=32x32x16 bf16 mixed precision, checkpointed Decoder"] = side_run(dev, 512, 32, 4, 2, True, "bf16")
-            oc["configs[4] geometry with the 'norm' checkpoint policy (conv outputs kept, only GroupNorm+swish re-made in the backward: more memory, "
-               "less recompute; NOT the unit-checkpointed configuration of the line above)"] = side_run(dev, 512, 32, 4, 2, "norm", "bf16")
-            oc["configs[3] 256x256 B=32 fp32, PatchGAN discriminator + LPIPS-style loss, both optimizers"] = side_run(dev, 256, 32, 4, 2, False, 32, gan=True)
-            oc["configs[1] shape in bf16, repeated after the 512x512 and GAN runs"] = side_run(dev, 256, 32, 30, 5, False, "bf16")
+            # short keys (they travel in the one stdout line); each entry's config.workload in bench_detail.json says what it ran
+            oc["bf16_256_B32"] = side_run(dev, 256, 32, 30, 5, False, "bf16")                       # configs[1] shape in bf16 mixed precision
+            oc["cfg4_bf16_512_ckpt_unit"] = side_run(dev, 512, 32, 4, 2, True, "bf16")               # configs[4]: 512x512, z=32x32x16, checkpointed Decoder
+            # configs[4] geometry with the 'norm' checkpoint policy (conv outputs kept, only GroupNorm+swish re-made in the backward: more
+            # memory, less recompute; NOT the unit-checkpointed configuration of the line above)
+            oc["cfg4_bf16_512_ckpt_norm"] = side_run(dev, 512, 32, 4, 2, "norm", "bf16")
+            oc["cfg3_f32_256_gan_lpips"] = side_run(dev, 256, 32, 4, 2, False, 32, gan=True)          # configs[3]: PatchGAN + LPIPS-style, both optimizers
+            oc["bf16_256_B32_again"] = side_run(dev, 256, 32, 30, 5, False, "bf16")                   # repeated after the 512x512 and GAN runs
             # the data-parallel path's overhead is the difference between THESE two adjacent runs (the headline ran first, on a cooler chip
             # and an empty allocator: a side run of the same step after the others has measured up to 1.7 % slower than it)
-            oc["configs[1] (256x256, B=32, fp32) repeated as a side run (single process), for the next line to compare with"] = \
-                side_run(dev, 256, 32, 6, 2, False, 32)
-            oc["configs[1] (256x256, B=32, fp32) through the data-parallel path: RCCL world size 1, bucketed reducer"] = \
-                side_run(dev, 256, 32, 6, 2, False, 32, force_dist=True)
+            oc["f32_256_B32_single"] = side_run(dev, 256, 32, 6, 2, False, 32)
+            oc["f32_256_B32_rccl_world1"] = side_run(dev, 256, 32, 6, 2, False, 32, force_dist=True)  # RCCL world size 1, bucketed reducer
             out["other_configs"] = oc
             try:
                 import torch.distributed as dist
@@ -670,7 +762,7 @@ def main():
             # BASELINE.json configs[0] beside it: the reference's own CPU-runnable case (64x64, B=2, 10 steps)
             out["cpu_baseline"]["config1"] = cpu_baseline(64, batch=2, steps=10, warmup=1)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd)
     if use_dist:
         dist.destroy_process_group()
 

@@ -41,3 +41,65 @@ def test_parent_does_not_touch_the_gpu():
     assert main.index("launch_ranks(args)") < main.index("torch.cuda")
     launch = src[src.index("def launch_ranks"):src.index("def launcher_selftest")]
     assert "torch.cuda" not in launch.replace("torch.cuda.*", "")
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("odvae_bench", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _no_constants(name):
+    raise AssertionError("non-strict JSON constant %s in the bench line" % name)
+
+
+def test_stdout_line_is_compact_strict_json(tmp_path):
+    """Round 4's line was 22.6 KB and the driver parsed nothing from it.  The ONE stdout line is built by compact_record() from the
+    full record; fed round 4's real full record (plus a NaN and an Infinity) it must stay under 4 KB, be strict JSON, and still
+    carry the contract's keys, `roofline`, `roofline_step` and `cpu_baseline`; per side run only value / ms_per_step / steps / dtype."""
+    b = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_record_final.json")))
+    full["host_over_gpu"] = float("nan")
+    full["roofline"]["traffic"] = float("inf")
+    full["other_configs"]["a failed side run"] = {"error": "RuntimeError: " + "x" * 5000}
+    line = b.compact_record(full, "bench_detail.json")
+    assert len(line) < 4096 and "\n" not in line
+    out = json.loads(line, parse_constant=_no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "ranks_joined", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_step", "cpu_baseline", "detail"):
+        assert k in out, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "kernel", "launches", "avg_launch_ms",
+              "share_of_step_time"):
+        assert k in out["roofline"], k
+    assert out["roofline"]["traffic"] is None            # Infinity -> null
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert out["config"]["workload"] and "model" not in out["config"]
+    for k, v in out["other_configs"].items():
+        assert set(v) <= {"value", "ms_per_step", "steps", "dtype", "error"}, (k, v)
+    # and the full record goes to a file as strict JSON, the line to the descriptor
+    r, w = os.pipe()
+    old_root = b.ROOT
+    b.ROOT = str(tmp_path)
+    try:
+        b.emit(full, w)
+    finally:
+        b.ROOT = old_root
+    os.close(w)
+    got = os.read(r, 1 << 16).decode()
+    os.close(r)
+    assert got.endswith("\n") and got.count("\n") == 1 and len(got) < 4096
+    json.loads(got, parse_constant=_no_constants)
+    detail = json.load(open(os.path.join(str(tmp_path), "bench_detail.json")), parse_constant=_no_constants)
+    assert detail["gpu_step_ms"]["all"] and "other_configs" in detail
+
+
+def test_compact_line_sheds_optional_blocks_before_the_limit():
+    b = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_record_final.json")))
+    full["other_configs"] = {"side run %03d %s" % (i, "y" * 60): {"value": 1.0, "ms_per_step": 2.0, "steps": 3, "dtype": "f32"} for i in range(60)}
+    line = b.compact_record(full, None)
+    assert len(line) <= b.LINE_LIMIT
+    out = json.loads(line, parse_constant=_no_constants)
+    assert "roofline" in out and "cpu_baseline" in out and "other_configs" not in out
