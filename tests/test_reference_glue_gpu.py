@@ -1,0 +1,227 @@
+"""The HIP path against outputs of the REFERENCE's own Python (tests/golden/reference_glue.npz, written in the build container by
+tests/golden/make_reference_goldens.py; tests/test_reference_glue.py holds the oracle to the same file on the CPU).
+
+Cases: DiagonalGaussianDistribution.kl (src/util/distributions.py:10-41), the dropout schedule (src/models/autoencoder.py:184-206),
+PoseLoss.forward for both optimizer indices over the three global_step regimes, the masked class id and an all-masked batch
+(src/modules/losses/contperceptual.py:214-375), PoseAutoencoder.training_step / validation_step (src/models/autoencoder.py:295-363).
+Everything below goes through the C ABI on cuda:0; nothing here imports the oracle.
+
+fp32 tolerances (relative to max|expected|; gradients to max(own norm, 1e-3 of the largest gradient norm of the case)), set to about 5x what
+the path was MEASURED to use on an MI355X (gpurun_out/r5_glue.log, copied to profiles/r05_reference_glue_margins.txt):
+  loss-only cases (LPIPS-style VGG stack + PatchGAN on 64x64 images): scalars 5e-6 (measured 8.4e-7), gradients 4e-5 (6.6e-6);
+  whole training / validation step (ch = 32 network + both loss networks): scalars 1.5e-5 (2.7e-6), gradients 1.5e-4 (2.9e-5).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, GOLD)
+from reference_cases import LABELS, LOSS_CASES, LOSS_KW, digest_of, loss_inputs, stats_table, step_batch  # noqa: E402
+
+YAML = os.path.join(GOLD, "autoencoder_kl_16x16x16.yaml")
+WORST = {}   # measured margins, printed by the last test (pytest -s) for profiles/r05_parity_margins
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "reference_glue.npz"))
+
+
+def relerr(a, b, atol=0.0):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a - b).max()) / (max(float(np.abs(b).max()), 1e-30) + atol) if b.size else 0.0
+
+
+def note(kind, e):
+    WORST[kind] = max(WORST.get(kind, 0.0), e)
+
+
+def check_scalar(kind, got, want, tol, what, atol=1e-6):
+    e = relerr(torch.as_tensor(got).float().reshape(np.shape(want)), want, atol=atol)
+    note(kind, e)
+    assert e <= tol, "%s: %.6g vs %.6g (rel %.2e > %.1e)" % (what, float(torch.as_tensor(got).float().reshape(-1)[0]), float(np.reshape(want, -1)[0]), e, tol)
+
+
+def check_param_grads(kind, gold, pre, named_params, tol, floor=1e-3, no_grad_prefix=None):
+    """no_grad_prefix: parameters that must have NO gradient here although the fixture holds one -- the discriminator's in a generator step
+    under the one-traversal adaptive weight.  The fixture was made without [PL-1.9] toggle_optimizer, so the reference's backward reaches
+    D's weights through g_loss; in training they are requires_grad=False during optimizer 0 and that gradient never exists.  The
+    three-pass form (ODVAE_ADAPTIVE_WEIGHT_ONE_PASS=0) produces it and is compared with the fixture."""
+    named_params = list(named_params)
+    top = max([float(gold["%s.gnorm.%s" % (pre, k)]) for k, _ in named_params if "%s.gnorm.%s" % (pre, k) in gold.files] or [0.0])
+    seen = 0
+    for k, p in named_params:
+        nk = "%s.gnorm.%s" % (pre, k)
+        if nk not in gold.files:
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-6 * max(top, 1.0), k
+            continue
+        gn = float(gold[nk])
+        scale = max(gn, floor * top, 1e-12)
+        if no_grad_prefix and k.startswith(no_grad_prefix):
+            assert p.grad is None, k
+            continue
+        if gn == 0.0 and p.grad is None:
+            continue    # the reference back-propagates an exact 0 (adopt_weight's 0 before disc_start); the product does not start that pass
+        assert p.grad is not None, k
+        e1 = abs(float(p.grad.double().norm()) - gn) / scale
+        head = gold["%s.ghead.%s" % (pre, k)]
+        got = p.grad.detach().cpu().reshape(-1)[:64].numpy().astype(np.float64)
+        e2 = float(np.abs(got - head).max()) / scale
+        note(kind, max(e1, e2))
+        assert max(e1, e2) <= tol, "grad %s: norm %.6g vs %.6g, head err %.2e (scale %.3g)" % (k, float(p.grad.double().norm()), gn, e2, scale)
+        seen += 1
+    return seen
+
+
+def test_kl_matches_the_reference(hip_lib, gold):
+    from odvae_amd.distributions import DiagonalGaussianDistribution as D
+    p4 = torch.from_numpy(gold["kl.self.params"]).to(DEV)
+    assert relerr(D(p4).kl(), gold["kl.self.out"]) < 1e-5
+    a, b = torch.from_numpy(gold["kl.other.params_self"]).to(DEV), torch.from_numpy(gold["kl.other.params_other"]).to(DEV)
+    out = D(a).kl(D(b))
+    assert tuple(out.shape) == (8,) and relerr(out, gold["kl.other.out"]) < 1e-5
+    assert relerr(D(a, deterministic=True).kl().cpu(), gold["kl.deterministic.out"]) == 0.0
+
+
+def _product_model(phase):
+    from odvae_amd import synthetic
+    model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=4, ch=32, phase=phase, perceptual_weight=1.0, disc_factor=1.0,
+                                  disc_start=0)
+    return model
+
+
+def test_dropout_schedule_matches_the_reference(hip_lib, gold):
+    model = _product_model("asis")
+    for s, want in zip(gold["dropout.steps"], gold["dropout.probs"]):
+        model._global_step = int(s)
+        assert model._get_dropout_prob() == pytest.approx(float(want), rel=0, abs=1e-15), int(s)
+
+
+def _product_loss():
+    from odvae_amd.losses import PoseLoss
+    from odvae_amd.synthetic import fill_state_procedural
+    torch.manual_seed(5)
+    loss = PoseLoss(dataset_stats=stats_table(), **LOSS_KW)
+    fill_state_procedural(loss, seed=31)
+    with torch.no_grad():
+        loss.logvar.fill_(0.3)
+    loss = loss.to(DEV).train()
+    return loss
+
+
+@pytest.mark.parametrize("one_pass", [True, False], ids=["one-pass-weight", "three-pass-weight"])
+@pytest.mark.parametrize("case", range(len(LOSS_CASES)), ids=[c[0] for c in LOSS_CASES])
+def test_pose_loss_forward_matches_the_reference(hip_lib, gold, case, one_pass):
+    """The product's PoseLoss (l1_masked_sum / gaussian_kl / pose_losses / PatchGAN / LPIPS-style kernels) on the reference's outputs, with
+    the adaptive weight taken both ways: the one-traversal form (default) and the reference's three backward passes."""
+    from odvae_amd import modules
+    from odvae_amd.distributions import DiagonalGaussianDistribution as D
+    from odvae_amd.synthetic import fill_state_procedural
+    name, gs, cls = LOSS_CASES[case]
+    loss = _product_loss()
+    loss.ONE_PASS = one_pass
+    assert sorted(loss.state_dict().keys()) == list(gold["loss.state_keys"])
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in loss_inputs(200 + case, cls).items()}
+    for opt in (0, 1):
+        pre = "loss.%s.opt%d" % (name, opt)
+        last = modules.Conv3x3(8, 3).to(DEV)          # the stand-in "decoder.conv_out": dec_obj = conv3x3(feat), last_layer = its weight
+        with torch.no_grad():
+            last.weight.copy_(d["last_w"])
+            last.bias.copy_(d["last_b"])
+        leaves = {k: d[k].clone().requires_grad_(True) for k in ("feat", "dec_pose", "moments", "bbox_moments")}
+        dec_obj = last(leaves["feat"])
+        with torch.no_grad():
+            fill_state_procedural(loss.discriminator, seed=31)
+        for p in loss.parameters():
+            p.grad = None
+        out, log = loss(d["rgb_gt"], None, d["pose_gt"], dec_obj, leaves["dec_pose"], d["class_id"], [LABELS[c] for c in cls], d["bbox_gt"],
+                        d["fill_factor_gt"], D(leaves["moments"]), D(leaves["bbox_moments"]), opt, gs, d["mask_2d_bbox"],
+                        last_layer=last.weight, split="train")
+        if pre + ".raises" in gold.files:
+            # DELIBERATE DEVIATION: the reference asserts on a training batch made of the masked class only (its nll is a
+            # graph-less 0); the product evaluates the same expressions on the device and gets d_weight = 0 / (||g|| + 1e-4) = 0
+            assert torch.isfinite(out).all() and float(log["train/d_weight"]) == 0.0 and float(log["train/nll_loss"]) == 0.0
+            continue
+        check_scalar("loss.scalar", out, gold[pre + ".loss"], 5e-6, pre + ".loss")
+        seen = 0
+        for k, v in log.items():
+            key = pre + ".log." + k
+            assert key in gold.files, k
+            check_scalar("loss.scalar", v, gold[key], 5e-6, key)
+            seen += 1
+        assert seen == len([f for f in gold.files if f.startswith(pre + ".log.")]), "the product logs every key the reference logs"
+        has_grads = any(f.startswith(pre + ".grad.") or f.startswith(pre + ".gnorm.") for f in gold.files)
+        if has_grads:
+            out.backward()
+            tops = [float(gold[pre + ".grad." + k + ".norm"]) for k in ("feat", "dec_pose", "moments", "bbox_moments")
+                    if pre + ".grad." + k + ".norm" in gold.files]
+            for k, t in list(leaves.items()) + [("last_w", last.weight), ("last_b", last.bias)]:
+                gkey = pre + ".grad." + k
+                if gkey + ".norm" not in gold.files:
+                    assert t.grad is None or float(t.grad.abs().max()) == 0.0, (pre, k)
+                    continue
+                norm, samples = digest_of(t.grad)
+                gn = float(gold[gkey + ".norm"])
+                scale = max(gn, 1e-3 * max(tops + [gn]), 1e-12)
+                e = max(abs(norm - gn) / scale, float(np.abs(samples.astype(np.float64) - gold[gkey + ".samples"]).max()) / scale)
+                note("loss.grad", e)
+                assert e <= 4e-5, "%s: norm %.6g vs %.6g (err %.2e)" % (gkey, norm, gn, e)
+            check_param_grads("loss.grad", gold, pre, loss.named_parameters(), 4e-5,
+                              no_grad_prefix="discriminator." if (one_pass and opt == 0) else None)
+
+
+@pytest.mark.parametrize("one_pass", [True, False], ids=["one-pass-weight", "three-pass-weight"])
+def test_training_and_validation_step_match_the_reference(hip_lib, gold, one_pass):
+    from odvae_amd.synthetic import fill_state_procedural
+    model = _product_model("vae")
+    model.loss.ONE_PASS = one_pass
+    assert sorted(model.state_dict().keys()) == list(gold["step.state_keys"])
+    opts, _ = model.configure_optimizers()
+    assert sum(q.numel() for g in opts[0].param_groups for q in g["params"]) == int(gold["step.opt0.nparams"])
+    assert sum(q.numel() for g in opts[1].param_groups for q in g["params"]) == int(gold["step.opt1.nparams"])
+    model = model.to(DEV).train()
+    batch = step_batch()
+    for opt_idx in (0, 1):
+        pre = "step.train.opt%d" % opt_idx
+        with torch.no_grad():
+            fill_state_procedural(model, seed=23)
+        from odvae_amd import ops
+        ops.PACK_CACHE.bump()
+        model._global_step = int(gold[pre + ".global_step"])
+        model.injected_noise = {k: torch.from_numpy(gold[pre + ".noise." + k]) for k in ("posterior_eps", "dropout_mask", "z_noise", "bbox_eps")}
+        model.zero_grad(set_to_none=True)
+        out = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0, opt_idx)
+        assert model.dropout_prob == pytest.approx(float(gold[pre + ".dropout_prob"]))
+        check_scalar("step.scalar", out, gold[pre + ".loss"], 1.5e-5, pre + ".loss")
+        logs = model.logged_metrics
+        want_keys = [f[len(pre + ".log."):] for f in gold.files if f.startswith(pre + ".log.")]
+        assert set(want_keys) <= set(logs.keys()), sorted(set(want_keys) - set(logs.keys()))
+        for k in want_keys:
+            check_scalar("step.scalar", logs[k], gold[pre + ".log." + k], 1.5e-5, pre + ".log." + k)
+        out.backward()
+        n = check_param_grads("step.grad", gold, pre, model.named_parameters(), 1.5e-4,
+                              no_grad_prefix="loss.discriminator." if (one_pass and opt_idx == 0) else None)
+        assert n > (200 if opt_idx == 0 else 10), n
+    with torch.no_grad():
+        fill_state_procedural(model, seed=23)
+    ops.PACK_CACHE.bump()
+    model.eval()
+    model._global_step = int(gold["step.val.global_step"])
+    model.injected_noise = {k: torch.from_numpy(gold["step.val.noise." + k]) for k in ("posterior_eps", "dropout_mask", "z_noise", "bbox_eps")}
+    with torch.no_grad():
+        model.validation_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0)
+    logs = model.logged_metrics
+    want_keys = [f[len("step.val.log."):] for f in gold.files if f.startswith("step.val.log.")]
+    assert "val/rec_loss" in want_keys and set(want_keys) <= set(logs.keys()), sorted(set(want_keys) - set(logs.keys()))
+    for k in want_keys:
+        check_scalar("step.scalar", logs[k], gold["step.val.log." + k], 1.5e-5, "step.val.log." + k)
+    print("reference-glue margins (worst relative deviation per class):", {k: "%.2e" % v for k, v in sorted(WORST.items())})
