@@ -22,12 +22,22 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // ---- row softmax ---------------------------------------------------------------------------------
 // AttnBlock.forward: w_ = softmax(bmm(q,k) * C^-0.5, dim=keys)  ([UPSTREAM] ldm .../model.py AttnBlock)
 // one block per row; cols % 4 == 0.  y may alias x.
+// Folded-softmax fallbacks taken since the library was loaded (odvae_device_health): a predicated softmax launch that found its flag set
+// counts itself once.  Not an error -- the fallback is exact -- but a run that takes it often is paying three extra passes per block.
+__device__ unsigned g_attn_fallbacks = 0;
+typedef __attribute__((address_space(1))) unsigned ew_gu32_t;
+__device__ __forceinline__ void count_fallback(const int* pred) {
+  if (pred && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_fetch_add((ew_gu32_t*)&g_attn_fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // pred (nullable): the launch does nothing unless *pred != 0; ones (nullable): ones[row] = 1 for every row done (the folded-softmax
 // fallback of ops.attention: the probabilities it writes are normalised, their row factor is 1)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, float* y, int64_t rows, int cols, float scale,
                                                            const int* pred, float* ones) {
   __shared__ float sh[8];
   if (pred && *pred == 0) return;
+  count_fallback(pred);
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     if (ones && threadIdx.x == 0) ones[row] = 1.f;
     const float* xr = x + row * cols;
@@ -99,6 +109,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* x, f
                                                                const int* pred, float* ones) {
   __shared__ float sh[8];
   if (pred && *pred == 0) return;
+  count_fallback(pred);
   for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
     if (ones && threadIdx.x == 0) ones[row] = 1.f;
     const float* xr = x + row * cols;
@@ -520,6 +531,17 @@ int odvae_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, flo
 int odvae_softmax_rows_pred_f32(const float* x, float* y, int64_t rows, int cols, float scale, const int* pred, float* ones, void* stream) {
   ODVAE_CHECK_ARG(pred && ones, "softmax_rows_pred: null predicate / row-factor array");
   return softmax_rows_impl(x, y, rows, cols, scale, pred, ones, stream);
+}
+
+// Device-side counter of the folded-softmax fallbacks; add > 0 is a TEST HOOK that bumps it (synchronises the device).  -1 on a HIP error.
+int odvae_attn_softmax_fallbacks(int add) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_attn_fallbacks), sizeof(v)) != hipSuccess) return -1;
+  if (add > 0) {
+    v += (unsigned)add;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_fallbacks), &v, sizeof(v)) != hipSuccess) return -1;
+  }
+  return (int)v;
 }
 
 // ---- folded attention softmax: the per-row bound of the scores, and the backward's row dot product with dO / l beside it ----

@@ -565,6 +565,34 @@ int odvae_groupnorm_fused_timeouts(void) {
   return (int)v;
 }
 
+int odvae_attn_softmax_fallbacks(int add);   // elementwise.hip
+
+// Both device-side health counters in one call (synchronises the device): gn_timeouts != 0 means a GroupNorm backward ran with a team
+// barrier that gave up -- its gradients are WRONG and the run must stop; attn_fallbacks counts exact-softmax fallbacks (correct, slower).
+// inject_gn_timeouts / inject_attn_fallbacks are TEST HOOKS: > 0 bumps the counter first, inject_gn_timeouts < 0 clears it.  ODVAE_ERR_HIP if a counter cannot be read.
+int odvae_device_health(int* gn_timeouts, int* attn_fallbacks, int inject_gn_timeouts, int inject_attn_fallbacks) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gn_fused_timeouts), sizeof(v)) != hipSuccess) {
+    odvae_set_error("device_health: cannot read the GroupNorm barrier counter");
+    return ODVAE_ERR_HIP;
+  }
+  if (inject_gn_timeouts != 0) {      // > 0: add (a simulated timeout); < 0: clear the counter (tests restore the state they found)
+    v = inject_gn_timeouts > 0 ? v + (unsigned)inject_gn_timeouts : 0u;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gn_fused_timeouts), &v, sizeof(v)) != hipSuccess) {
+      odvae_set_error("device_health: cannot write the GroupNorm barrier counter");
+      return ODVAE_ERR_HIP;
+    }
+  }
+  const int f = odvae_attn_softmax_fallbacks(inject_attn_fallbacks > 0 ? inject_attn_fallbacks : 0);
+  if (f < 0) {
+    odvae_set_error("device_health: cannot read the folded-softmax fallback counter");
+    return ODVAE_ERR_HIP;
+  }
+  if (gn_timeouts) *gn_timeouts = (int)v;
+  if (attn_fallbacks) *attn_fallbacks = f;
+  return ODVAE_OK;
+}
+
 // y = act(GroupNorm(x)); mean/rstd [N][G] are outputs (saved for backward).  swish: 0 = identity, 1 = x*sigmoid(x)
 int odvae_groupnorm_fwd_f32(const float* x, int N, int HW, int C, int G, const float* gamma, const float* beta,
                             float eps, int swish, float* y, float* mean, float* rstd,

@@ -20,7 +20,7 @@ void odvae_set_error(const char* fmt, ...) {
 const char* odvae_last_error(void) { return g_err; }
 
 // ABI version of include/odvae_hip.h this library was built against
-int odvae_abi_version(void) { return 3; }
+int odvae_abi_version(void) { return 4; }
 
 const char* odvae_target_arch(void) { return "gfx950"; }
 

@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "odvae_hip.h")
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
-ABI_VERSION = 3   # == ODVAE_ABI_VERSION in include/odvae_hip.h; bumped whenever the exported surface changes
+ABI_VERSION = 4   # == ODVAE_ABI_VERSION in include/odvae_hip.h; bumped whenever the exported surface changes
 
 # name -> (restype, argtypes); mirrors include/odvae_hip.h one to one (tests/test_abi.py checks that)
 PROTOTYPES = {
@@ -71,6 +71,8 @@ PROTOTYPES = {
     "odvae_groupnorm_bwd_partials_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "odvae_groupnorm_select_backward": (_I, [_I]),
     "odvae_groupnorm_fused_timeouts": (_I, []),
+    "odvae_device_health": (_I, [_P, _P, _I, _I]),
+    "odvae_attn_softmax_fallbacks": (_I, [_I]),
     "odvae_softmax_rows_f32": (_I, [_P, _P, _L, _I, _F, _P]),
     "odvae_softmax_rows_bwd_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "odvae_upsample2x_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

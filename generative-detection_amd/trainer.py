@@ -15,6 +15,10 @@ import torch
 from .parallel import GradReducer
 
 
+class DeviceHealthError(RuntimeError):
+    """A HIP kernel reported, through the library's device-side health counters, that it produced wrong numbers."""
+
+
 class _TrainerHandle:
     """What `model.trainer` exposes to the module (the optimizer list drives PL-style toggling)."""
 
@@ -55,6 +59,9 @@ class Trainer:
                 o.materialize()
         model.trainer = _TrainerHandle(opts)
         self.current_epoch = 0            # completed passes over the training loader (PL: trainer.current_epoch)
+        # device-side health counters as of the last check_device_health(): GroupNorm team-barrier timeouts (fatal) and exact-softmax
+        # fallbacks of the folded attention softmax (correct, slower; reported)
+        self.device_health = {"gn_barrier_timeouts": 0, "attn_softmax_fallbacks": 0}
         self.callback_metrics = {}        # name -> 0-d CPU tensor: the last validate()'s epoch means (what ModelCheckpoint monitors)
         self.reducers = None
         if distributed is None:
@@ -119,6 +126,38 @@ class Trainer:
             cb.on_train_batch_end(self, model, losses, batch, batch_idx)
         return losses
 
+    def check_device_health(self, where=""):
+        """Reads the library's two device-side counters (odvae_device_health: one device synchronisation, so it is called only where the
+        host waits anyway -- validation, checkpoint save, the end of fit).  A GroupNorm backward whose team barrier gave up has written
+        WRONG gradients (csrc/groupnorm.hip: the opt-in team mode, odvae_groupnorm_select_backward(1)): DeviceHealthError, and no
+        checkpoint is written from such a state.  Fallbacks of the folded attention softmax are exact; new ones since the last check are
+        reported once through `warnings` and to the logger's `log_metrics` when it has one.  Returns the counters."""
+        import ctypes
+        import warnings
+        from . import lib as _lib
+        if not torch.cuda.is_available():
+            return dict(self.device_health)
+        L = _lib.load()
+        gn, at = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(L.odvae_device_health(ctypes.byref(gn), ctypes.byref(at), 0, 0), "device_health")
+        prev = self.device_health
+        self.device_health = {"gn_barrier_timeouts": int(gn.value), "attn_softmax_fallbacks": int(at.value)}
+        if gn.value > prev["gn_barrier_timeouts"]:
+            raise DeviceHealthError(
+                "%d GroupNorm team-barrier wait(s) gave up on the device%s (global_step %d): the gradients of those launches are wrong. "
+                "The team mode is opt-in (odvae_groupnorm_select_backward(1)); the default never waits across blocks."
+                % (gn.value - prev["gn_barrier_timeouts"], (" before " + where) if where else "", int(self.model.global_step)))
+        if at.value > prev["attn_softmax_fallbacks"]:
+            new = at.value - prev["attn_softmax_fallbacks"]
+            warnings.warn("%d attention block(s) took the exact-softmax fallback since the last check (global_step %d): a row's Cauchy-Schwarz "
+                          "bound underflowed in f32; results are exact, each fallback costs three extra passes over its T x T scores"
+                          % (new, int(self.model.global_step)), RuntimeWarning, stacklevel=2)
+            logger = getattr(self.model, "logger", None) or getattr(self.model, "_odvae_logger", None)
+            log = getattr(logger, "log_metrics", None)
+            if log is not None:
+                log({"device/attn_softmax_fallbacks": float(at.value)}, step=int(self.model.global_step))
+        return dict(self.device_health)
+
     def fit(self, batches, max_batches=None, val_batches=None, max_epochs=1):
         """`max_epochs` passes over `batches` (re-iterated per epoch; at most `max_batches` each).  With `val_batches` every epoch
         ends as PL's does: validation over the whole loader, `on_validation_end` (ModelCheckpoint saves here), then the epoch counter
@@ -133,6 +172,7 @@ class Trainer:
             if val_batches is not None:
                 self.validate(val_batches)
             self._set_epoch(self.current_epoch + 1)
+        self.check_device_health("the end of fit")
         return out
 
     def _set_epoch(self, epoch):
@@ -175,7 +215,8 @@ class Trainer:
                     cb.on_validation_batch_end(self, model, out, batch, i)
         finally:
             model.train(was_training)
-        metrics = {k: (sums[k] / counts[k]).float().cpu() for k in sums}
+        metrics = {k: (sums[k] / counts[k]).float().cpu() for k in sums}      # (the host waits for the device here anyway)
+        self.check_device_health("validation ended")
         self.callback_metrics.update(metrics)
         for cb in self.callbacks:
             hook = getattr(cb, "on_validation_end", None)
@@ -214,6 +255,7 @@ class Trainer:
 
     def save_checkpoint(self, path, weights_only=False):
         """Rank 0 writes `path` (atomically: temporary file + rename); every rank returns the path."""
+        self.check_device_health("writing %s" % os.path.basename(path))      # never a checkpoint of weights stepped with wrong gradients
         if _rank() == 0:
             os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
             tmp = "%s.part" % path

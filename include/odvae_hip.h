@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ODVAE_ABI_VERSION 3            /* odvae_abi_version() of a library built from this header */
+#define ODVAE_ABI_VERSION 4            /* odvae_abi_version() of a library built from this header */
 #define ODVAE_OK 0
 #define ODVAE_ERR_ARG 1
 #define ODVAE_ERR_WORKSPACE 2
@@ -186,6 +186,12 @@ int odvae_groupnorm_bwd_partials_f32(const float* x, const float* dy, int N, int
 int odvae_groupnorm_select_backward(int mode);
 /* team-barrier waits of the read-once kernels that gave up (0.2 s) since the library was loaded; synchronises the device.  Must be 0. */
 int odvae_groupnorm_fused_timeouts(void);
+/* both device-side health counters (synchronises the device; call where the host waits anyway: validation, checkpoint, end of fit):
+ * *gn_timeouts != 0 -> a GroupNorm backward's team barrier gave up and its gradients are WRONG (stop the run); *attn_fallbacks = exact-softmax
+ * fallbacks of the folded attention softmax taken so far (correct results, three extra passes each).  inject_* > 0: test hooks that bump the
+ * counters first (inject_gn_timeouts < 0 clears that counter).  Mirrors nothing in the reference (its torch ops cannot fail this way); generative-detection_amd/trainer.py reads it. */
+int odvae_device_health(int* gn_timeouts, int* attn_fallbacks, int inject_gn_timeouts, int inject_attn_fallbacks);
+int odvae_attn_softmax_fallbacks(int add);
 /* dx_add (nullable, same shape as x): a second gradient reaching x (the ResnetBlock / AttnBlock skip connection,
    [UPSTREAM] model.py `return x + h`), summed into dx in the same pass instead of autograd's separate add kernel */
 

@@ -28,7 +28,7 @@ def test_binding_table_matches_header(built_lib):
 
 def test_identification_calls(built_lib):
     handle = built_lib.load()
-    assert handle.odvae_abi_version() == built_lib.ABI_VERSION == 3
+    assert handle.odvae_abi_version() == built_lib.ABI_VERSION == 4
     assert handle.odvae_target_arch() == b"gfx950"
     # pure host queries (no kernel launch)
     assert handle.odvae_conv3x3_pack_reduce_pad(3) == 32 and handle.odvae_conv3x3_pack_out_pad(3) == 32

@@ -22,21 +22,20 @@ def main():
     model = synthetic.build_model(YAML, batch_size_for_lr=12, latent_hw=16).to(dev).train()
     model._global_step = 1
     trainer = Trainer(model, gradient_clip_val=1.0, optimizer_indices=(0,), precision="bf16" if bf16 else None)
-    losses, flags = [], []
+    losses = []
+    fallbacks0 = _lib.load().odvae_attn_softmax_fallbacks(0)
     alloc0 = None
     for i in range(steps):
         batch = synthetic.make_batch(32, 256, seed=1000 + i)
         batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
         loss = trainer.training_batch(batch, i)[0]
         losses.append(loss.detach())
-        if ops._ATTN_LAST_FLAG is not None:
-            flags.append(ops._ATTN_LAST_FLAG)
         if i == 5:
             alloc0 = torch.cuda.memory_stats(dev)["num_device_alloc"]
     torch.cuda.synchronize()
     ls = [float(x) for x in losses]
     assert all(l == l and abs(l) < 1e30 for l in ls), "non-finite loss"
-    n_flag = sum(int(f.item()) for f in set(flags))
+    n_flag = _lib.load().odvae_attn_softmax_fallbacks(0) - fallbacks0     # the device-side counter: every attention block of every step
     timeouts = _lib.load().odvae_groupnorm_fused_timeouts()
     allocs = torch.cuda.memory_stats(dev)["num_device_alloc"] - alloc0
     k = max(1, steps // 6)
