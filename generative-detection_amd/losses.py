@@ -108,7 +108,7 @@ class LPIPSWithDiscriminator(nn.Module):
     # The reference takes two partial backward passes (nll_loss and g_loss, each down to the decoder's last layer) for the adaptive weight
     # and then a full one through the same graph: the LPIPS-style VGG stack and the discriminator are back-propagated TWICE per generator
     # step.  Backpropagation is linear in the incoming gradient, so one traversal is enough: take d nll / d x_rec and d g_loss / d x_rec
-    # once, get the two last-layer gradients from them (only conv_out's own backward runs), and hand the main backward pass the combined
+    # once, get the two last-layer gradients from them (only conv_out's own weight-gradient launch runs: ops.weight_gradient_only), and hand the main backward pass the combined
     # gradient at x_rec through a surrogate term -- same values, same parameter gradients (to summation order), one VGG and one
     # discriminator backward less (≈ 5 % of a configs[3] step).  ODVAE_ADAPTIVE_WEIGHT_ONE_PASS=0 keeps the reference's three passes.
     ONE_PASS = os.environ.get("ODVAE_ADAPTIVE_WEIGHT_ONE_PASS", "1") != "0"
@@ -117,8 +117,9 @@ class LPIPSWithDiscriminator(nn.Module):
         """(d_weight, g_nll, g_g): the adaptive weight of calculate_adaptive_weight and the two gradients w.r.t. the reconstruction."""
         g_nll = torch.autograd.grad(nll_loss, reconstructions, retain_graph=True)[0]
         g_g = torch.autograd.grad(g_loss, reconstructions, retain_graph=True)[0]
-        nll_grads = torch.autograd.grad(reconstructions, last_layer, grad_outputs=g_nll, retain_graph=True)[0]
-        g_grads = torch.autograd.grad(reconstructions, last_layer, grad_outputs=g_g, retain_graph=True)[0]
+        with ops.weight_gradient_only():      # (needs_input_grad is fixed at forward time: without this each probe also runs conv_out's data gradient)
+            nll_grads = torch.autograd.grad(reconstructions, last_layer, grad_outputs=g_nll, retain_graph=True)[0]
+            g_grads = torch.autograd.grad(reconstructions, last_layer, grad_outputs=g_g, retain_graph=True)[0]
         d_weight = torch.norm(nll_grads) / (torch.norm(g_grads) + 1e-4)
         d_weight = torch.clamp(d_weight, 0.0, 1e4).detach()
         return d_weight * self.discriminator_weight, g_nll, g_g

@@ -5,6 +5,7 @@ parameters (checkpoint interchange with the reference) and are r
 torch supplies device memory, the current stream and autograd bookkeeping; every FLOP and every byte
 of the hot path moves through libodvae_hip.so.  No CPU fallback exists.
 """
+import contextlib
 import os
 import weakref
 
@@ -313,6 +314,22 @@ def _conv_issued(mode, n, hi, wi, ho, wo, cin, cout):
 
 # Stride-1 3x3 convs by Winograd F(2x2, 3x3) (conv3x3_wino_f32.hip) when the shape allows; ODVAE_CONV_WINOGRAD=0 keeps
 # the direct implicit-GEMM kernel everywhere
+# True inside `weight_gradient_only()`: the 3x3 conv Functions skip their data gradient.  torch fixes ctx.needs_input_grad at FORWARD time, so a
+# torch.autograd.grad(y, weight, grad_outputs=g) probe would otherwise also run (and throw away) the layer's data-gradient launch: the two
+# last-layer probes of the adaptive weight (losses.adaptive_weight_one_pass) need decoder.conv_out's weight gradient only.
+WEIGHT_GRADIENT_ONLY = False
+
+
+@contextlib.contextmanager
+def weight_gradient_only():
+    global WEIGHT_GRADIENT_ONLY
+    prev, WEIGHT_GRADIENT_ONLY = WEIGHT_GRADIENT_ONLY, True
+    try:
+        yield
+    finally:
+        WEIGHT_GRADIENT_ONLY = prev
+
+
 WINOGRAD = os.environ.get("ODVAE_CONV_WINOGRAD", "1") != "0"
 # Weight gradient of those convs in the Winograd domain (conv3x3_wgrad_wino_f32.hip) where the shape allows (even H, W,
 # channel counts in multiples of 128); ODVAE_WGRAD_WINOGRAD=0 keeps the direct weight-gradient kernel everywhere
@@ -483,7 +500,7 @@ class _Conv3x3(Function):
         n, _, hi, wi = x.shape
         _, _, ho, wo = dy.shape
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not WEIGHT_GRADIENT_ONLY:
             PACK_CACHE.check_epoch(ctx.pack_epoch, "conv3x3 backward")
             _, dgr = pack_conv3x3(weight, False, True, "wino4" if ctx.up == "wino4up" else ctx.up)
             if ctx.up == "wino4up" and UPCONV_POOLED_DGRAD:
@@ -1557,7 +1574,7 @@ class _ConvB(Function):
         else:
             dyb = _cl(dy, BF16)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not WEIGHT_GRADIENT_ONLY:
             if cx != cin:
                 raise NotImplementedError("data gradient through a channel-padded input")
             PACK_CACHE.check_epoch(ctx.pack_epoch, "conv_bf16 backward")

@@ -230,3 +230,61 @@ def test_lpips_from_upstream_keyed_checkpoint(hip_lib, tmp_path):
     model2 = instantiate_from_config(mcfg2).to(DEV)
     with pytest.warns(RuntimeWarning, match="SYNTHETIC"):
         model2.loss._check_perceptual_weights()
+
+
+@pytest.mark.parametrize("ckpt", [False, "unit", "norm"], ids=["no-ckpt", "ckpt-unit", "ckpt-norm"])
+@pytest.mark.parametrize("precision", [32, "bf16"], ids=["f32", "bf16"])
+def test_one_pass_adaptive_weight_equals_the_three_pass_form(hip_lib, precision, ckpt):
+    """The generator step's adaptive weight from ONE traversal of the LPIPS-style VGG stack and the discriminator (losses.PoseLoss,
+    ODVAE_ADAPTIVE_WEIGHT_ONE_PASS, the default) against the reference's three backward passes ([UPSTREAM] calculate_adaptive_weight:
+    two partial passes to decoder.conv_out.weight, then the full one; contperceptual.py:294-301) on the SAME model, batch and noise:
+    d_weight, the total, and the gradient of every autoencoder parameter and of loss.logvar.  Backpropagation is linear in the incoming
+    gradient, so the two differ by summation order at the reconstruction only: f32 1e-5 (every tensor holding >= 1e-4 of the gradient energy,
+    relative to its largest entry; and the relative L2 difference of the whole gradient); under bf16 activations that f32 difference flips
+    bf16 roundings downstream (5e-2 per tensor as in tests/test_bf16_model_gpu.py, 2e-2 on the whole gradient).  With every decoder checkpoint policy, because the 'norm'
+    policy re-makes conv_out's input on each of the backward calls.  The discriminator and the frozen LPIPS-style net get NO gradient in
+    the one-pass form (under [PL-1.9] toggle_optimizer they are requires_grad = False during optimizer 0 anyway); both forms are held
+    to the reference's own outputs in tests/test_reference_glue_gpu.py."""
+    import os
+    from test_model_gpu import build_pair
+    from odvae_amd import synthetic
+    yaml_noise = synthetic.make_noise(2, 4, dropout_p=0.7, seed=31)
+    batch = synthetic.make_batch(2, 64, seed=30)
+    grads, scalars = {}, {}
+    for one_pass in (True, False):
+        model, _ = build_pair(perceptual_weight=1.0, disc_factor=1.0, activation_checkpoint=ckpt)
+        model.set_precision(precision)
+        model.train()
+        model.loss.ONE_PASS = one_pass
+        model._global_step = 2
+        model.injected_noise = yaml_noise
+        loss = model.training_step({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}, 0, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        scalars[one_pass] = (float(loss), float(model.logged_metrics["train/d_weight"]), float(model.logged_metrics["train/g_loss"]))
+        grads[one_pass] = {k: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+        if one_pass:
+            for k, g in grads[True].items():
+                if k.startswith("loss.discriminator") or k.startswith("loss.perceptual_loss"):
+                    assert g is None, k
+            assert grads[True]["loss.logvar"] is not None
+    tol, tol_l2 = (1e-5, 1e-5) if precision == 32 else (5e-2, 2e-2)     # measured: f32 2.0e-6 / 9.7e-7; bf16 1.7e-2 / 8.7e-3
+    for a, b in zip(scalars[True], scalars[False]):
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (scalars[True], scalars[False])
+    assert scalars[False][1] > 0.0                                  # the weight is live, not the eval-mode 0
+    # per tensor: every tensor that holds >= 1e-4 of the gradient energy, relative to its own largest entry (a conv bias in front of a GroupNorm
+    # has a near-zero gradient made of cancellation noise: such tensors are judged through the whole-gradient measures below only)
+    keys = [k for k, g in grads[False].items() if g is not None and not (k.startswith("loss.discriminator") or k.startswith("loss.perceptual_loss"))]
+    for k in keys:
+        assert grads[True][k] is not None, k
+    energy = {k: float(grads[False][k].double().pow(2).sum()) for k in keys}
+    total = sum(energy.values())
+    errs = sorted(((float((grads[True][k].double() - grads[False][k].double()).abs().max()) / max(float(grads[False][k].abs().max()), 1e-30), k)
+                   for k in keys if energy[k] >= 1e-4 * total), reverse=True)
+    a = torch.cat([grads[True][k].double().reshape(-1) for k in keys])
+    b = torch.cat([grads[False][k].double().reshape(-1) for k in keys])
+    rel_l2 = float((a - b).norm() / b.norm())
+    print("one-pass vs three-pass adaptive weight (%s, ckpt=%s): %d tensors, %d above 1e-4 of the energy, worst of those %.2e (%s); whole gradient "
+          "relative L2 difference %.2e" % (precision, ckpt, len(keys), len(errs), errs[0][0], errs[0][1], rel_l2))
+    assert len(keys) > 200 and len(errs) >= 20
+    assert errs[0][0] <= tol and rel_l2 <= tol_l2, (errs[:3], rel_l2)
