@@ -200,11 +200,20 @@ class ModelCheckpoint(Callback):
         return name.format(**vals)
 
     def _path(self, trainer, metrics):
+        """The file name of this save; an existing file of that name that is not one of ours gets a -v<k> suffix ([PL-1.9] versioning).
+        Only rank 0 writes, so only rank 0 looks at the disk; under data parallelism it broadcasts its answer, and `best_k_models` (part
+        of `state_dict()`) holds the same keys on every rank."""
         base = self.format_checkpoint_name(metrics)
         path, v = os.path.join(self.dirpath or ".", base + ".ckpt"), 0
-        while os.path.exists(path) and path not in self.best_k_models:
-            v += 1
-            path = os.path.join(self.dirpath or ".", "%s-v%d.ckpt" % (base, v))
+        if _is_rank_zero():
+            while os.path.exists(path) and path not in self.best_k_models:
+                v += 1
+                path = os.path.join(self.dirpath or ".", "%s-v%d.ckpt" % (base, v))
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [path]
+            dist.broadcast_object_list(box, src=0)
+            path = box[0]
         return path
 
     def on_validation_end(self, trainer, pl_module):

@@ -185,9 +185,11 @@ class Trainer:
     # ---- validation (src/models/autoencoder.py:332-363; [PL-1.9] evaluation loop) -----------------------------------------------
     @torch.no_grad()
     def validate(self, batches, max_batches=None):
-        """model.eval(), `validation_step` per batch under no_grad, every logged scalar averaged over the batches (PL's default for
-        `self.log` inside validation_step is on_epoch=True with the mean as the reduction); `val/rec_loss` is logged with
-        `sync_dist=True` (:359), so each batch value already is the mean over the ranks.  The epoch means land in
+        """model.eval(), `validation_step` per batch under no_grad, every logged scalar averaged over the epoch the way [PL-1.9] does it
+        for `self.log(..., on_epoch=True)` inside validation_step: the mean WEIGHTED BY BATCH SIZE (ResultMetric: value * batch_size
+        summed, divided by the cumulated batch size; the batch size is the first dimension of the first tensor in the batch,
+        `extract_batch_size`) -- with a ragged last batch this is what the reference's ModelCheckpoint(monitor) sees;
+        `val/rec_loss` is logged with `sync_dist=True` (:359), so each batch value already is the mean over the ranks.  The epoch means land in
         `self.callback_metrics` (and are returned); callbacks see `on_validation_batch_end` per batch and `on_validation_end` once.
         The model's training mode is restored."""
         model = self.model
@@ -202,6 +204,7 @@ class Trainer:
                 if logged is not None:
                     logged.clear()
                 out = model.validation_step(batch, i)
+                bs = _batch_size(batch)
                 for k, v in (getattr(model, "logged_metrics", None) or {}).items():
                     if torch.is_tensor(v):
                         if v.numel() != 1:
@@ -209,8 +212,9 @@ class Trainer:
                         v = v.detach().double().reshape(())
                     else:
                         v = torch.tensor(float(v), dtype=torch.float64)
+                    v = v * bs
                     sums[k] = v if k not in sums else sums[k] + v.to(sums[k].device)      # stays on the device: no sync per batch
-                    counts[k] = counts.get(k, 0) + 1
+                    counts[k] = counts.get(k, 0) + bs
                 for cb in self.callbacks:
                     cb.on_validation_batch_end(self, model, out, batch, i)
         finally:
@@ -263,11 +267,21 @@ class Trainer:
             os.replace(tmp, path)
         return path
 
-    def load_checkpoint(self, path, strict=True):
+    def load_checkpoint(self, path, strict=True, trusted=False):
         """Resume from a checkpoint in that layout -- one of this trainer's or one Lightning wrote for the reference model: weights
         (strict by default), `global_step`, `epoch`, and the optimizer states when present (a weights-only file leaves the
-        optimizers fresh, as Lightning does)."""
-        ckpt = torch.load(path, map_location="cpu")
+        optimizers fresh, as Lightning does).  The file is read with torch's restricted unpickler (`weights_only=True`: tensors, numbers,
+        strings, containers).  A real Lightning checkpoint may also carry arbitrary Python objects (`hyper_parameters` as an OmegaConf
+        DictConfig, callback state with timedelta / Path): unpickling those executes code, so it happens only with `trusted=True`."""
+        import pickle
+        try:
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            if not trusted:
+                raise pickle.UnpicklingError(
+                    "%s holds objects torch's restricted unpickler refuses (%s). If the file comes from a source you trust -- a Lightning "
+                    "checkpoint with hyper_parameters / callback state -- call load_checkpoint(path, trusted=True)." % (path, str(e).splitlines()[0])) from e
+            ckpt = torch.load(path, map_location="cpu", weights_only=False)
         res = self.model.load_state_dict(ckpt["state_dict"], strict=strict)
         from . import ops
         ops.PACK_CACHE.bump()           # load_state_dict copies into .data of the arena views: no version bump the pack cache could see
@@ -280,6 +294,21 @@ class Trainer:
             for o, sd in zip(self.optimizers, states):
                 o.load_state_dict(sd)
         return res
+
+
+def _batch_size(batch):
+    """[PL-1.9] extract_batch_size: the first dimension of the first tensor found in the batch (dicts / sequences walked in order); 1 if none."""
+    if torch.is_tensor(batch):
+        return int(batch.shape[0]) if batch.dim() > 0 else 1
+    if isinstance(batch, dict):
+        batch = list(batch.values())
+    if isinstance(batch, (list, tuple)):
+        for v in batch:
+            if torch.is_tensor(v):
+                return int(v.shape[0]) if v.dim() > 0 else 1
+            if isinstance(v, (dict, list, tuple)) and any(torch.is_tensor(x) for x in (v.values() if isinstance(v, dict) else v)):
+                return _batch_size(v)
+    return 1
 
 
 def _rank():

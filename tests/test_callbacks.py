@@ -4,6 +4,7 @@ pixel values of the grids, torchvision's make_grid layout rule, and that every `
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.nn as nn
 
@@ -186,3 +187,49 @@ def test_modelcheckpoint_keeps_the_three_best_and_last(tmp_path):
     assert torch.equal(model2.lin.weight, model.lin.weight)
     s1, s2 = trainer.optimizers[0].state_dict()["state"], trainer2.optimizers[0].state_dict()["state"]
     assert all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) and float(s1[k]["step"]) == float(s2[k]["step"]) == 15.0 for k in s1)
+
+
+def test_validation_means_are_weighted_by_batch_size():
+    """[PL-1.9] reduces an on_epoch `self.log` inside validation_step as sum(value * batch_size) / sum(batch_size) (ResultMetric), not as the
+    plain mean over batches: with a ragged last batch the two differ, and the monitored `val/rec_loss` decides which checkpoints survive
+    (train.py:238-241).  Three batches of 4, 4 and 1 samples with per-batch values 1.0, 2.0, 10.0: PL's mean is 22 / 9, the plain one 13 / 3."""
+    from odvae_amd.trainer import Trainer, _batch_size
+    model = _TinyVal([1.0])
+    vals = iter([1.0, 2.0, 10.0])
+
+    def validation_step(batch, batch_idx, _m=model):
+        v = torch.tensor(next(vals))
+        _m.log("val/rec_loss", v, sync_dist=True)
+        _m.log_dict({"val/other": 2 * v})
+    model.validation_step = validation_step
+    trainer = Trainer(model, optimizer_indices=(0,))
+    got = trainer.validate([torch.randn(4, 4), torch.randn(4, 4), torch.randn(1, 4)])
+    assert abs(float(got["val/rec_loss"]) - 22.0 / 9.0) < 1e-6 and abs(float(got["val/other"]) - 44.0 / 9.0) < 1e-6
+    assert _batch_size({"class_name": ["car"] * 3, "patch": torch.zeros(5, 3, 8, 8), "yaw": torch.zeros(7)}) == 5
+    assert _batch_size([{"a": torch.zeros(6, 2)}, torch.zeros(2)]) == 6 and _batch_size({"names": ["x"]}) == 1
+
+
+def test_load_checkpoint_refuses_pickled_objects_unless_trusted(tmp_path):
+    """torch >= 2.6 loads with weights_only=True by default; a Lightning checkpoint may carry arbitrary objects (hyper_parameters as an OmegaConf
+    DictConfig, callback state).  load_checkpoint reads tensor-only files as is and unpickles objects only when the caller says `trusted`."""
+    import pathlib
+    import pickle
+    from odvae_amd.trainer import Trainer
+    model = _TinyVal([0.5])
+    trainer = Trainer(model, optimizer_indices=(0,))
+    ckpt = trainer.dump_checkpoint()
+    # the full PL-1.9 key set around it: loops, callbacks keyed by PL's ModelCheckpoint state_key, hyper_parameters
+    ckpt["loops"] = {"fit_loop": {"state_dict": {}, "epoch_progress": {"current": {"completed": 3}}}}
+    ckpt["callbacks"] = {"ModelCheckpoint{'monitor': 'val/rec_loss', 'mode': 'min', 'every_n_train_steps': 0, 'every_n_epochs': 1, "
+                         "'train_time_interval': None}": {"best_model_score": torch.tensor(0.25), "best_model_path": "/logs/x/epoch=000003.ckpt"}}
+    ckpt["hyper_parameters"] = {"embed_dim": 16, "monitor": "val/rec_loss"}
+    plain = os.path.join(tmp_path, "plain.ckpt")
+    torch.save(ckpt, plain)
+    trainer.load_checkpoint(plain)                                   # tensors, numbers, strings, containers: the restricted unpickler takes it
+    ckpt["callbacks"]["Timer"] = {"where": pathlib.PurePosixPath("/logs/x")}    # an object of a class outside torch's allow-list
+    objs = os.path.join(tmp_path, "objects.ckpt")
+    torch.save(ckpt, objs)
+    with pytest.raises(pickle.UnpicklingError, match="trusted=True"):
+        trainer.load_checkpoint(objs)
+    trainer.load_checkpoint(objs, trusted=True)
+    assert model.global_step == ckpt["global_step"]
