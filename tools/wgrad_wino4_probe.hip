@@ -1,29 +1,21 @@
-// DESIGN.md §7's next kernel in a first form: the stride-1 3x3 weight gradient in the F(4x4,3x3) domain (the arithmetic: tools/wgrad_wino4_math.py).
-// NOT part of the library (written and run in the last GPU minutes of round 4): a standalone program that checks itself against a CPU loop
-// (ragged H, W) and times the 128 -> 128 @256^2 layer; results in profiles/r04_wgrad_wino4_probe.txt.
+// The stride-1 3x3 weight gradient in the F(4x4,3x3) domain (the arithmetic: tools/wgrad_wino4_math.py) as a standalone, self-checking
+// program -- a NEGATIVE RESULT, kept as the record of it (rounds 4-5); not part of the library.
 //   dW[co][ci] = Aw^T [ sum_tiles (Gw dy Gw^T) .* (B^T x B) ] Aw       per 4x4 output tile, 36 products instead of 144
-// Blocking (the forward kernel's, as sized in DESIGN.md): a block owns all 36 xi x 64 co x 32 ci of the transform-domain sum (8 waves: wave =
-// (xi group of 9, co half of 32), nine 32 x 32 accumulators = 144 registers) over a contiguous range of tiles, 8 tiles per chunk:
-//   every thread transforms one (tile, co) pair of dy (4x4 -> 6x6) and threads 0..255 one (tile, ci) pair of x (6x6 -> 6x6) per chunk,
-//   U [36][8][64] and V [36][8][32] go to LDS (110.6 KB), then 4 k-steps x 9 xi of v_mfma_f32_32x32x2_f32 per wave (k = tile); the next
-//   chunk's operands are fetched into registers before the MFMAs.  255 VGPRs, no spills, 2 waves per SIMD.
-// Grid = (Cout / 64) x (Cin / 32) x splits; a second kernel sums the splits and applies Aw^T . Aw.
-// Measured (B = 8, 128 -> 128 @256^2, 32 splits; check 3.0e-6 of max|dW| in every form):
-//   fetch -> transform -> multiply in sequence                          0.933 ms
-//   THIS FORM (operands of the next chunk fetched before the MFMAs)      0.771 ms = 200 TFLOP/s direct-equivalent, the rate of the library's
-//                                                                        F(2x2)-domain kernel (204)
-//   two 4-tile LDS stages, waves 0-3 dy / waves 4-5 x, the two waves of a SIMD in opposite phases (one transforms while the other
-//   multiplies)                                                          0.921 ms (two SIMDs carry 37 % more vector work)
-//   the same with x staged 8 tiles over waves 4-7 (balanced; 147.5 KB)   0.827 ms (git show e75c537:tools/wgrad_wino4_probe.hip)
-// The opposite-phase forms did NOT overlap matrix and vector work (as tools/mfma_valu_coexec_probe.hip found for bf16): the bound is the sum of
-// the two, and the way on is less vector work.  -DWGW4_NEXT=1 builds the two next steps, written after the GPU minutes ran out and NOT YET
-// RUN (the program's own check will tell): the tile -> (n, ty, tx) decode by a float reciprocal with a one-step correction instead of two
-// integer divisions per fetch (~100 of ~650 vector instructions per chunk on waves 0-3), and the sum over splits by 36 Cout Cin / 256 blocks
-// instead of Cout Cin / 256 (the finish kernel is ~0.1 ms of the numbers above; 64 / 128 splits cost +0.21 / +0.72 ms through it).
-// Build: hipcc --offload-arch=gfx950 -O3 [-DWGW4_NEXT=1] tools/wgrad_wino4_probe.hip -o tools/bin/wgrad_wino4 ; run on the GPU box: tools/bin/wgrad_wino4
-#ifndef WGW4_NEXT
-#define WGW4_NEXT 0
-#endif
+// Blocking (the forward kernel's): a block owns all 36 xi x 64 co x 32 ci of the transform-domain sum (8 waves: wave = (xi group of 9,
+// co half of 32), nine 32 x 32 accumulators = 144 registers) over a contiguous range of tiles, 8 tiles per chunk: every thread transforms one
+// (tile, co) pair of dy (4x4 -> 6x6) and threads 0..255 one (tile, ci) pair of x (6x6 -> 6x6) per chunk, U [36][8][64] and V [36][8][32] go
+// to LDS (110.6 KB), then 4 k-steps x 9 xi of v_mfma_f32_32x32x2_f32 per wave (k = tile); the next chunk's operands are fetched into
+// registers before the MFMAs.  Tile decode by a float reciprocal with a one-step correction; the sum over splits by its own kernel.
+// Grid = (Cout / 64) x (Cin / 32) x splits; two more kernels sum the splits and apply Aw^T . Aw.
+// Measured on one MI355X at B = 32 against the library's F(2x2)-domain kernel (odvae_conv3x3_wgrad_wino_f32), profiles/r05_wgrad_wino4_probe.txt:
+//   128->128 @256^2  2.39 ms vs 2.14      128->128 @128^2  0.68 vs 0.57      256->256 @64^2  0.72 vs 0.55      512->512 @32^2 0.71 (library @16^2: 0.16)
+// i.e. 10-30 % SLOWER on every layer shape of the step although it issues 1.78x fewer MFMAs: each transformed value is reused by only 32 (ci)
+// or 64 (co) accumulator columns and BOTH operands are transformed per chunk (the forward kernel transforms one, its weights arrive
+// pre-transformed), ~900 vector instructions per SIMD and chunk beside 72 MFMAs -- and on gfx950 the f32 MFMA and the vector ALU share
+// their issue cycles (profiles/r02_wino8_loop.md), so the transform time ADDS to the matrix time.  Forms tried: fetch -> transform ->
+// multiply in sequence 0.933 ms (B = 8), next chunk's operands fetched before the MFMAs 0.771-0.780, two 4-tile LDS stages with the two waves
+// of a SIMD in opposite phases 0.827-0.921 (no overlap of matrix and vector work), reciprocal tile decode + parallel split sum 0.674.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/wgrad_wino4_probe.hip -o tools/bin/wgrad_wino4 ; run: tools/bin/wgrad_wino4 [N H W Cin Cout splits...]
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -71,7 +63,6 @@ __device__ __forceinline__ void gw6(const float g[4], float o[6]) {
 // tile index -> image, tile row, tile column
 __device__ __forceinline__ void decode_tile(const Params& p, int t, int& n, int& ty, int& tx) {
   const int per_img = p.TY * p.TX;
-#if WGW4_NEXT
   // t < 2^24 is exact in a float and the rounded product is off by at most one: one correction step each way
   int q = (int)((float)t * p.inv_per_img);
   int r = t - q * per_img;
@@ -82,12 +73,6 @@ __device__ __forceinline__ void decode_tile(const Params& p, int t, int& n, int&
   if (r2 < 0) { --q2; r2 += p.TX; }
   if (r2 >= p.TX) { ++q2; r2 -= p.TX; }
   n = q; ty = q2; tx = r2;
-#else
-  n = t / per_img;
-  const int r = t - n * per_img;
-  ty = r / p.TX;
-  tx = r - ty * p.TX;
-#endif
 }
 
 __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
@@ -293,13 +278,9 @@ static Run run(int N, int H, int W, int Cin, int Cout, int splits_want, const st
   for (int it = 0; it < reps + 1; ++it) {
     if (it == 1) HIP_OK(hipEventRecord(e0));
     hipLaunchKernelGGL(wgrad_wino4_kernel, dim3(Cout / CO_B, Cin / CI_B, splits), dim3(512), lds, 0, p);
-#if WGW4_NEXT
     const int64_t n36 = (int64_t)NXI * Cout * Cin;
     hipLaunchKernelGGL(wgrad_wino4_sum_kernel, dim3((unsigned)((n36 + 255) / 256)), dim3(256), 0, 0, dpart, splits, n36);
     hipLaunchKernelGGL(wgrad_wino4_finish_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, 0, dpart, 1, Cout, Cin, ddw);
-#else
-    hipLaunchKernelGGL(wgrad_wino4_finish_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, 0, dpart, splits, Cout, Cin, ddw);
-#endif
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
@@ -316,7 +297,20 @@ static void fill(std::vector<float>& v, unsigned seed, float scale) {
   for (auto& f : v) { s = s * 1664525u + 1013904223u; f = scale * ((float)((s >> 8) & 0xFFFF) / 32768.f - 1.f); }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc >= 6) {      // timing of one layer shape: N H W Cin Cout [splits...]; device-side fill is not needed: the host vectors are a few GB at most
+    const int N = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]);
+    std::vector<float> x((size_t)N * H * W * Cin), dy((size_t)N * H * W * Cout);
+    fill(x, 3, 1.f); fill(dy, 4, 1e-3f);
+    for (int a = 6; a < argc || a == 6; ++a) {
+      const int splits = a < argc ? atoi(argv[a]) : 64;
+      Run r = run(N, H, W, Cin, Cout, splits, x, dy, 20);
+      const double flop = 2.0 * 9 * N * H * W * (double)Cin * Cout;
+      printf("B%d %d->%d @%dx%d splits %d: %.3f ms, %.1f TFLOP/s direct-equivalent (%.1f issued)\n", N, Cin, Cout, H, W, splits, r.ms, flop / r.ms * 1e-9, flop / 4 / r.ms * 1e-9);
+      if (a >= argc) break;
+    }
+    return 0;
+  }
   {      // check against a CPU loop (ragged H, W: the last tile row / column is partly outside)
     const int N = 2, H = 18, W = 27, Cin = 64, Cout = 128;
     std::vector<float> x((size_t)N * H * W * Cin), dy((size_t)N * H * W * Cout);
