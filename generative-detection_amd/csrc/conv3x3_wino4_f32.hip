@@ -75,7 +75,8 @@ __device__ __forceinline__ float lds_ld32f(unsigned a) { return *(const __attrib
 __device__ __forceinline__ void lds_st32f(unsigned a, float v) { *(__attribute__((address_space(3))) float*)(uintptr_t)a = v; }
 // -DODVAE_W4_ABL=<bits>: timing-only ablation builds (results are wrong): 1 no output transform, 2 no input transform in the loop,
 // 4 no weight refills, 8 no A-fragment reads, 16 no halo DMA in the loop, 32 no wait for the DMA at the end of a chunk, 64 no barrier,
-// 128 epilogue without the stores, 256 without the LDS exchange, 512 without its barriers, 1024 every other weight refill only
+// 128 epilogue without the stores, 256 without the LDS exchange, 512 without its barriers, 1024 every other weight refill only,
+// 2048 no output transform at all
 #ifndef ODVAE_W4_ABL
 #define ODVAE_W4_ABL 0
 #endif
@@ -327,8 +328,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(Wino4Params p) {
   const int cstep = p.Cout * 4, rstep = (POOL ? p.W >> 1 : p.W) * p.Cout * 4;
   const unsigned x_wr = (unsigned)(X0 + ((ct * 36 + 9 * g) * 4 * 64 + lane_e) * 4);
   const unsigned x_rd = (unsigned)(X0 + ((ct2 * 36 * 4 + e2) * 64 + lane_e) * 4);
+  if (ODVAE_W4_ABL & 2048) {      // timing only: no output transform at all (the accumulators are consumed by one guarded store)
+    float sacc = 0.f;
 #pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc += acc[j][r];
+    if (sacc == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sacc), yrsrc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rq = 0; rq < ((ODVAE_W4_ABL & 2048) ? 0 : 4); ++rq) {
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll

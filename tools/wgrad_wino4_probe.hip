@@ -36,7 +36,7 @@ struct Params {
   const float* dy;      // [N][H][W][Cout]
   float* partial;       // [splits][36][Cout][Cin]
   int N, H, W, Cin, Cout, TY, TX, tiles, tiles_per_split;
-  float inv_per_img, inv_tx;      // WGW4_NEXT: reciprocals for the tile decode (tiles < 2^24, host-checked)
+  float inv_per_img, inv_tx;      // reciprocals for the tile decode (tiles < 2^24, host-checked)
 };
 
 // B^T d for one line of six (the forward kernel's input transform)
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void wgrad_wino4_kernel(Params p) {
   }
 }
 
-// WGW4_NEXT: the sum over splits on its own, one thread per (xi, co, ci), into split 0's slab (every thread reads and writes its own element only)
+// the sum over splits on its own, one thread per (xi, co, ci), into split 0's slab (every thread reads and writes its own element only)
 __global__ void wgrad_wino4_sum_kernel(float* partial, int splits, int64_t n36) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n36) return;
