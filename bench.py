@@ -79,6 +79,8 @@ def compact_record(full, detail_path=None):
                                   for e in full["roofline_others"]]
     if isinstance(full.get("cpu_baseline"), dict):
         out["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+        if full["cpu_baseline"].get("cores_busy") is not None:
+            out["cpu_baseline"]["cores_busy"] = _r(full["cpu_baseline"]["cores_busy"], 3)
         if isinstance(full["cpu_baseline"].get("config1"), dict):
             out["cpu_baseline"]["config1"] = _pick(full["cpu_baseline"]["config1"], ("value", "cores", "sample"))
     if isinstance(full.get("other_configs"), dict):
@@ -191,13 +193,20 @@ def cpu_baseline(res, batch=1, steps=1, warmup=1):
     noise = synthetic.make_noise(batch, lat, seed=24)
     for _ in range(warmup):
         train_batch(ref, opts, batch_d, {0: noise}, optimizer_indices=(0,), clip=1.0)
+    cg0, c0 = cgroup_cpu(), os.times()
     t0 = time.time()
     for _ in range(steps):
         train_batch(ref, opts, batch_d, {0: noise}, optimizer_indices=(0,), clip=1.0)
     dt = time.time() - t0
+    cg1, c1 = cgroup_cpu(), os.times()
+    cpu_s = (c1.user - c0.user) + (c1.system - c0.system)
+    # cores_busy: CPU seconds this process burnt per wall second of the timed leg -- what "cores" really delivered (a quota-throttled or
+    # oversubscribed host shows here, and in the cgroup's throttle counters, not in the thread count)
     return {"value": batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d warm-up + %d timed step(s), B=%d, %dx%d, fp32, rec+KL only, torch %s CPU oracle"
-                      % (warmup, steps, batch, res, res, torch.__version__)}
+                      % (warmup, steps, batch, res, res, torch.__version__),
+            "wall_s": dt, "cores_busy": cpu_s / dt if dt > 0 else None,
+            "cgroup_cpu_delta": {k: cg1[k] - cg0[k] for k in cg1 if k in cg0}}
 
 
 def host_enqueue_ms(step, first_index, reps=3):
@@ -640,7 +649,7 @@ def main():
         if roof is not None:
             traffic = None   # HBM bytes per launch of the same kernel, from committed rocprofv3 --pmc passes of this command
             tfile = None
-            for cand in (("r04_bf16_conv_traffic.json",) if args.bf16 else ("r04_conv3x3_traffic.json",)):   # this round's PMC passes only
+            for cand in (("r05_bf16_conv_traffic.json",) if args.bf16 else ("r05_conv3x3_traffic.json",)):   # this round's PMC passes only
                 if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                     tfile = cand
                     break
@@ -708,7 +717,7 @@ def main():
                               "algorithmic_bytes_per_step": r["bytes_per_launch"] * r["launches"],
                               "note": "algorithmic bytes = x read + y written (forward), x, dy (, skip gradient) read + dx written (backward)"})
                     # this round's PMC passes only: a file from before a kernel change is not evidence for these kernels
-                    fam = os.path.join(ROOT, "profiles", "r04_family_traffic.json")
+                    fam = os.path.join(ROOT, "profiles", "r04_family_traffic.json")      # (the GroupNorm kernels are unchanged since these passes)
                     if not (args.gan or args.bf16 or args.ckpt_decoder) and args.res == 256 and args.batch == 32 and os.path.exists(fam):
                         # HBM bytes the family actually moves (statistics / reduce are passes of their own), from the committed PMC
                         # passes of this command (FETCH_SIZE x2 + WRITE_SIZE over `steps_counted` steps), over the time measured live here

@@ -27,6 +27,17 @@ def test_gpus2_launches_two_ranks():
     assert out["ranks_in_lockstep"] is True and out["selftest"] is True
 
 
+def test_gpus8_launch_path_on_gloo():
+    """The N = 8 case of the driver's SCALE run, rehearsed on host tensors (8 gloo ranks on this container's cores): the parent starts
+    eight ranks, all eight join, the bucketed reducer keeps them in lockstep, and ONE compact strict-JSON line comes back."""
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "0", "--launcher-selftest"], timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, lines
+    out = json.loads(lines[0], parse_constant=_no_constants)
+    assert out["n_gpus"] == 8 and out["ranks_joined"] == 8 and out["ranks_in_lockstep"] is True
+
+
 def test_world_size_mismatch_is_an_error():
     # a launcher that started a different number of ranks than --gpus names must not pass silently
     r = _run(["--gpus", "4", "--launcher-selftest"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
