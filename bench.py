@@ -402,6 +402,11 @@ def side_run(dev, res, batch, steps, warmup, ckpt, precision, gan=False, force_d
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats(dev)
         dt, host, diag = timed_loop(step, warmup, steps, dev)
+        if force_dist and trainer.reducers:      # one more step, outside the timed loop, with the bucket schedule recorded (events on the compute stream)
+            trainer.reducers[0].record_timeline = True
+            step(warmup + steps)
+            diag["dp_bucket_timeline"] = trainer.reducers[0].timeline()
+            trainer.reducers[0].record_timeline = False
         host1 = host_enqueue_ms(step, warmup + steps)
         out = {"value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                "host_enqueue_ms_per_step": host1, "host_over_gpu": host1 / (dt / steps * 1e3), "host_loop_ms_per_step": host / steps * 1e3,

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False, comm_dtype=None, f32_accumulate=False):
+    def __init__(self, optimizer, process_group=None, bucket_mb=32.0, prescaled=False, comm_dtype=None, f32_accumulate=False, first_bucket_mb=1.0):
         """prescaled=True: the caller back-propagates `loss * inv_world` (trainer.Trainer does), so the summed buckets
         already ARE the mean and finish() needs no averaging pass over the arena (284 MB for optimizer 0).
         comm_dtype=torch.bfloat16: a bucket travels as bf16 -- cast into a staging buffer when its last gradient lands, all-reduced
@@ -30,7 +30,11 @@ class GradReducer:
         all-to-all of its world-many shards (rank r receives shard r of every rank, as bf16), the world shards summed in f32 on the rank
         that owns them, ONE rounding of the sum to bf16, all-gather of the reduced shards.  The second half of a bucket is issued when the
         next bucket starts (or in finish()), so both halves overlap with the rest of the backward pass.  Backends without all-to-all
-        (gloo, in the CPU tests) take the same arithmetic through all-gathers."""
+        (gloo, in the CPU tests) take the same arithmetic through all-gathers.
+        first_bucket_mb: size of the bucket at the FRONT of the arena -- the first parameters of the model (encoder.conv_in, down.0 ...), whose
+        gradients the backward produces LAST.  Its collective cannot hide behind anything, so it is kept small, as torch DDP keeps its first
+        bucket at 1 MB: measured on the f32 step (bench.py's RCCL world-size-1 side run, `dp_bucket_timeline`) seven of eight 32 MB buckets are
+        ready 88-97 ms into a 152 ms backward and the front one -- 35 MB before this split -- at 152 ms, i.e. its whole all-reduce was exposed."""
         self.group = process_group
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.f32_accumulate = bool(f32_accumulate) and self.comm_dtype is not None
@@ -55,6 +59,7 @@ class GradReducer:
         self.slices = slices
         # buckets: runs of consecutive parameters, ~bucket_mb each
         limit = int(bucket_mb * 1024 * 1024 / 4)
+        first_limit = min(limit, max(1, int(first_bucket_mb * 1024 * 1024 / 4)))
         self.buckets = []       # (start, end) in arena elements
         self.param_bucket = {}
         start, count, members = None, 0, []
@@ -63,7 +68,7 @@ class GradReducer:
                 start = off
             members.append(i)
             end = slices[i + 1][1] if i + 1 < len(slices) else self.arena.numel()
-            if end - start >= limit or i + 1 == len(slices):
+            if end - start >= (limit if self.buckets else first_limit) or i + 1 == len(slices):
                 b = len(self.buckets)
                 self.buckets.append((start, end))
                 for m in members:
@@ -79,6 +84,11 @@ class GradReducer:
         self._launched = set()
         self._touched_buckets = set()
         self.launch_order = []   # bucket ids in the order their collectives were issued (tests look at this)
+        # record_timeline = True (a diagnostic, off by default): one event on the compute stream when the backward starts, one per bucket at the
+        # moment its collective is issued (= its last gradient's kernel is queued), one when finish() returns -- `timeline()` turns them into
+        # "bucket b (n MB) ready k ms into a backward of K ms", the schedule an N-rank run overlaps its collectives with
+        self.record_timeline = False
+        self._tl = None
         for i, (p, _, _) in enumerate(slices):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
 
@@ -98,6 +108,21 @@ class GradReducer:
         self._launched = set()
         self._touched_buckets = set()
         self.launch_order = []
+        if self.record_timeline and self.arena.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._tl = {"start": ev, "buckets": [], "end": None}
+
+    def timeline(self):
+        """After finish() of a backward recorded with `record_timeline`: {"backward_ms", "buckets": [{"bucket", "mbytes", "ready_ms"}]} (one
+        device synchronisation).  ready_ms counts from prepare_for_backward() on the compute stream."""
+        tl = self._tl
+        if not tl or tl["end"] is None:
+            return None
+        tl["end"].synchronize()
+        return {"backward_ms": tl["start"].elapsed_time(tl["end"]),
+                "buckets": [{"bucket": b, "mbytes": (self.buckets[b][1] - self.buckets[b][0]) * 4 / 1e6, "ready_ms": tl["start"].elapsed_time(ev)}
+                            for b, ev in tl["buckets"]]}
 
     def _on_grad(self, i):
         if self._pending is None:
@@ -114,6 +139,10 @@ class GradReducer:
             self.optimizer.gather_grads(self.bucket_members[b])
         self._launched.add(b)
         self.launch_order.append(b)
+        if self._tl is not None and self.record_timeline:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._tl["buckets"].append((b, ev))
         if self.comm_dtype is None:
             self._works.append(dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -185,6 +214,10 @@ class GradReducer:
                 s, e = self.buckets[b]
                 self.arena[s:e].mul_(self.inv_world)
         self._pending = None
+        if self._tl is not None and self.record_timeline:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._tl["end"] = ev
 
     # ---- start-up ------------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, module):

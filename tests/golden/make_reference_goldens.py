@@ -275,7 +275,7 @@ def model_kwargs(phase):
     return p, f.name
 
 
-def replay_draws(seed, B, latent, p_drop, add_noise=True):
+def replay_draws(seed, B, latent, p_drop, add_noise=True, perturbed=False):
     """The host RNG stream of ONE reference forward (autoencoder.py:227-244), replayed call by call after the same manual_seed:
     posterior randn, nn.Dropout's mask, Normal(0,1).sample, bbox-posterior randn."""
     torch.manual_seed(seed)
@@ -284,7 +284,10 @@ def replay_draws(seed, B, latent, p_drop, add_noise=True):
     mask = torch.nn.functional.dropout(torch.ones(shape), p_drop, True) if p_drop > 0 else torch.ones(shape)
     zn = torch.distributions.normal.Normal(0, 1).sample(shape) if add_noise else torch.zeros(shape)
     beps = torch.randn(B, 8)
-    return {"posterior_eps": eps, "dropout_mask": mask, "z_noise": zn, "bbox_eps": beps}
+    out = {"posterior_eps": eps, "dropout_mask": mask, "z_noise": zn, "bbox_eps": beps}
+    if perturbed:      # log_images: _perturbed_pose_forward samples the posterior once more (autoencoder.py:387-390)
+        out["posterior_eps_perturbed"] = torch.randn(shape)
+    return out
 
 
 def case_dropout_schedule(arrays, ref_ae):
@@ -364,6 +367,21 @@ def case_steps(arrays, ref_ae):
         arrays["step.val.noise." + k] = np_(v)
     for k, v in model.logged.items():
         arrays["step.val.log." + k] = np_(torch.as_tensor(v).float())
+    # log_images (:397-432): no graph, forward + the perturbed-pose decode; the three image sets as digests
+    fill_state_procedural(model, seed=23)
+    model.global_step = 9
+    del DRAWS[:]
+    torch.manual_seed(903)
+    imgs = model.log_images(ref_batch())
+    noise = replay_draws(903, B, 4, model.dropout_prob, perturbed=True)
+    assert len(DRAWS) == 3 and torch.equal(DRAWS[0], noise["posterior_eps"]) and torch.equal(DRAWS[1], noise["bbox_eps"]) \
+        and torch.equal(DRAWS[2], noise["posterior_eps_perturbed"])
+    arrays["step.images.global_step"] = np.int64(9)
+    for k, v in noise.items():
+        arrays["step.images.noise." + k] = np_(v)
+    assert sorted(imgs) == ["inputs_rgb", "perturbed_pose_reconstruction_rgb", "reconstructions_rgb"]
+    for k, v in imgs.items():
+        digest(arrays, "step.images." + k, v)
 
 
 def main():

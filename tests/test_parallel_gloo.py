@@ -189,3 +189,36 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     assert r0["nb5"] >= 2 and torch.equal(r0["g5"], r1["g5"])
     exact5 = (r0["local5"].to(torch.bfloat16).float() + r1["local5"].to(torch.bfloat16).float()).to(torch.bfloat16).float() * 0.5
     assert torch.equal(r0["g5"], exact5)
+
+
+def test_front_bucket_is_small():
+    """The bucket at the front of the arena holds the model's first parameters -- the gradients a backward pass produces LAST -- so its
+    collective is the one nothing can hide; like torch DDP's 1 MB first bucket it is cut small (GradReducer(first_bucket_mb=...)).  Layout only:
+    single process, gloo group of one."""
+    import torch.distributed as dist
+    from odvae_amd.parallel import GradReducer
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        own = True
+    else:
+        own = False
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(*[torch.nn.Linear(256, 256) for _ in range(8)])      # 8 x 65 792 parameters = 0.25 MB each
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        red = GradReducer(opt, bucket_mb=1.0, first_bucket_mb=0.25)
+        sizes = [(e - s) * 4 / 2 ** 20 for s, e in red.buckets]
+        assert sizes[0] <= 0.27 and all(x >= 1.0 for x in sizes[1:-1]), sizes
+        assert sum(e - s for s, e in red.buckets) == red.arena.numel() and red.buckets[0][0] == 0
+        # the front bucket is the LAST one whose collective is issued
+        red.prepare_for_backward()
+        net(torch.randn(4, 256)).sum().backward()
+        red.finish()
+        assert red.launch_order[-1] == 0 and sorted(red.launch_order) == list(range(len(red.buckets))), red.launch_order
+        same = GradReducer(torch.optim.SGD(net.parameters(), lr=0.1), bucket_mb=1.0, first_bucket_mb=1.0)
+        assert (same.buckets[0][1] - same.buckets[0][0]) * 4 / 2 ** 20 >= 1.0
+    finally:
+        if own:
+            dist.destroy_process_group()

@@ -225,3 +225,35 @@ def test_training_and_validation_step_match_the_reference(hip_lib, gold, one_pas
     for k in want_keys:
         check_scalar("step.scalar", logs[k], gold["step.val.log." + k], 1.5e-5, "step.val.log." + k)
     print("reference-glue margins (worst relative deviation per class):", {k: "%.2e" % v for k, v in sorted(WORST.items())})
+
+
+def test_log_images_match_the_reference(hip_lib, gold):
+    """`log_images` (src/models/autoencoder.py:397-432: forward without a graph, then `_perturbed_pose_forward` with the yaw of
+    `yaw_perturbed` written over the decoded pose and one more posterior sample) as the reference ran it; the three image sets by norm and
+    by 2 048 strided samples each (tests/golden/reference_cases.digest_of).  f32 bound 1e-4 of the largest pixel (measured below)."""
+    from odvae_amd import ops
+    from odvae_amd.synthetic import fill_state_procedural
+    model = _product_model("vae").to(DEV).eval()
+    with torch.no_grad():
+        fill_state_procedural(model, seed=23)
+    ops.PACK_CACHE.bump()
+    model._global_step = int(gold["step.images.global_step"])
+    model.injected_noise = {k: torch.from_numpy(gold["step.images.noise." + k])
+                            for k in ("posterior_eps", "dropout_mask", "z_noise", "bbox_eps", "posterior_eps_perturbed")}
+    batch = step_batch()
+    imgs = model.log_images({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    assert sorted(imgs) == ["inputs_rgb", "perturbed_pose_reconstruction_rgb", "reconstructions_rgb"]
+    worst = 0.0
+    for k, v in imgs.items():
+        assert tuple(v.shape) == (4, 3, 64, 64) and not v.requires_grad
+        norm, samples = digest_of(v)
+        want = gold["step.images." + k + ".samples"]
+        scale = max(float(np.abs(want).max()), 1e-30)
+        e = max(abs(norm - float(gold["step.images." + k + ".norm"])) / max(float(gold["step.images." + k + ".norm"]), 1e-30),
+                float(np.abs(samples.astype(np.float64) - want).max()) / scale)
+        worst = max(worst, e)
+    print("log_images vs the reference: worst relative deviation %.2e" % worst)
+    assert worst <= 1e-4, worst
+    # the perturbed-pose image differs from the plain reconstruction (the yaw was replaced), the input is the rescaled patch
+    assert (imgs["perturbed_pose_reconstruction_rgb"] - imgs["reconstructions_rgb"]).abs().max().item() > 1e-3
+    assert abs(imgs["inputs_rgb"].max().item() - 1.0) < 1e-6 and abs(imgs["inputs_rgb"].min().item() + 1.0) < 1e-6
