@@ -262,9 +262,10 @@ def case_loss(arrays, ref_loss, ref_dist):
     arrays["loss.state_keys"] = np.array(sorted(loss.state_dict().keys()))
 
 
-def model_kwargs(phase):
+def model_kwargs(phase, latent_hw=4, ch=32, perceptual_weight=1.0, disc_factor=1.0):
     from odvae_amd import synthetic
-    mcfg, _ = synthetic.model_config(YAML, latent_hw=4, ch=32, phase=phase, perceptual_weight=1.0, disc_factor=1.0, disc_start=0)
+    mcfg, _ = synthetic.model_config(YAML, latent_hw=latent_hw, ch=ch, phase=phase, perceptual_weight=perceptual_weight, disc_factor=disc_factor,
+                                     disc_start=0)
     p = mcfg.params.to_container()
     stats = p["lossconfig"]["params"].pop("dataset_stats")
     f = tempfile.NamedTemporaryFile(suffix=".pkl", delete=False)
@@ -384,6 +385,38 @@ def case_steps(arrays, ref_ae):
         digest(arrays, "step.images." + k, v)
 
 
+def case_headline(arrays, ref_ae):
+    """BASELINE.json configs[1] itself, as far as the CPU allows: the yaml's OWN network (ch = 128, 71 M parameters in optimizer 0, 4 096 attention
+    tokens) at 256 x 256, rec+KL only (perceptual_weight = 0, disc_factor = 0), B = 2, one training_step of optimizer 0 at global_step 1 run by the
+    reference's PoseAutoencoder.training_step / PoseLoss.forward, backward by autograd: loss, logged terms, per-parameter gradient digests.  Weights
+    follow from the state_dict keys (fill_state_procedural), the batch from synthetic.make_batch(2, 256, seed=5), the noise is stored."""
+    from odvae_amd import synthetic
+    from odvae_amd.synthetic import fill_state_procedural
+    p, path = model_kwargs("vae", latent_hw=16, ch=None, perceptual_weight=0.0, disc_factor=0.0)
+    torch.manual_seed(3)
+    model = ref_ae.PoseAutoencoder(**p)
+    os.unlink(path)
+    fill_state_procedural(model, seed=23)
+    model.train()
+    model.global_step = 1
+    batch = synthetic.make_batch(2, 256, seed=5)
+    del DRAWS[:]
+    torch.manual_seed(910)
+    out = model.training_step({k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in batch.items()}, 0, 0)
+    noise = replay_draws(910, 2, 16, model.dropout_prob)
+    assert len(DRAWS) == 2 and torch.equal(DRAWS[0], noise["posterior_eps"]) and torch.equal(DRAWS[1], noise["bbox_eps"])
+    pre = "headline.train.opt0"
+    arrays[pre + ".dropout_prob"] = np.float64(model.dropout_prob)
+    for k, v in noise.items():
+        arrays[pre + ".noise." + k] = np_(v)
+    arrays[pre + ".loss"] = np_(out)
+    for k, v in model.logged.items():
+        arrays[pre + ".log." + k] = np_(torch.as_tensor(v).float())
+    out.backward()
+    grad_digest(arrays, pre, model.named_parameters())
+    arrays["headline.nparams"] = np.int64(sum(q.numel() for q in model.parameters()))
+
+
 def main():
     torch.set_num_threads(4)
     install_standins()
@@ -393,6 +426,7 @@ def main():
     case_dropout_schedule(arrays, ref_ae)
     case_loss(arrays, ref_loss, ref_dist)
     case_steps(arrays, ref_ae)
+    case_headline(arrays, ref_ae)
     np.savez_compressed(OUT, **arrays)
     print("wrote %s: %d arrays, %d bytes" % (OUT, len(arrays), os.path.getsize(OUT)))
 

@@ -206,3 +206,32 @@ def test_training_and_validation_step_match_the_reference(gold):
     assert "val/rec_loss" in logs and "val/disc_loss" in logs
     for k, v in logs.items():
         assert close(torch.as_tensor(v).float(), gold["step.val.log." + k], atol=1e-12), (k, float(v), float(gold["step.val.log." + k]))
+
+
+def test_headline_network_step_matches_the_reference(gold):
+    """BASELINE.json configs[1]'s own network (ch = 128, 256 x 256, 4 096 attention tokens, rec+KL only) at B = 2: the reference's training_step run on
+    the oracle's Encoder / Decoder against the oracle's own training_step -- loss, logged terms, every parameter gradient (1e-4 of max(own norm,
+    1e-3 of the largest): f32 sums in a different thread count)."""
+    from odvae_amd import synthetic
+    from odvae_amd.synthetic import fill_state_procedural
+    from oracle.autoencoder import PoseAutoencoder
+    mcfg, _ = synthetic.model_config(YAML, latent_hw=16, ch=None, phase="vae", perceptual_weight=0.0, disc_factor=0.0, disc_start=0)
+    p = mcfg.params.to_container()
+    model = PoseAutoencoder(p["ddconfig"], dict(p["lossconfig"]["params"]), p["embed_dim"], p["pose_decoder_config"]["params"],
+                            p["pose_encoder_config"]["params"], feat_dims=p.get("feat_dims", [16, 16, 16]), dropout_prob_init=p["dropout_prob_init"],
+                            dropout_prob_final=p["dropout_prob_final"], dropout_warmup_steps=p["dropout_warmup_steps"],
+                            pose_conditioned_generation_steps=p["pose_conditioned_generation_steps"],
+                            add_noise_to_z_obj=p["add_noise_to_z_obj"], train_on_yaw=p["train_on_yaw"])
+    assert sum(q.numel() for q in model.parameters()) == int(gold["headline.nparams"])
+    fill_state_procedural(model, seed=23)
+    model.train()
+    model.global_step = 1
+    pre = "headline.train.opt0"
+    noise = {k: torch.from_numpy(gold[pre + ".noise." + k]) for k in ("posterior_eps", "dropout_mask", "z_noise", "bbox_eps")}
+    out, log, _ = model.training_step(synthetic.make_batch(2, 256, seed=5), 0, noise)
+    assert close(out, gold[pre + ".loss"]), (float(out), float(gold[pre + ".loss"]))
+    for k, v in log.items():
+        assert close(torch.as_tensor(v).float(), gold[pre + ".log." + k], atol=1e-12), (k, float(v), float(gold[pre + ".log." + k]))
+    out.backward()
+    n = check_param_grads(gold, pre, model.named_parameters(), rtol=1e-4, floor=1e-3)
+    assert n > 250, n
