@@ -112,7 +112,7 @@ def _json_safe(o):
     return o
 
 
-def emit(full, json_fd):
+def emit(full, json_fd, name="bench_detail.json"):
     """Full record -> bench_detail.json beside this script (and a copy under gpurun_out/ when that directory exists, so a gpurun call
     brings it home) and stderr stays free of it; the compact line -> the saved stdout descriptor."""
     rel = None
@@ -120,9 +120,9 @@ def emit(full, json_fd):
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
             try:
-                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                with open(os.path.join(d, name), "w") as f:
                     json.dump(full, f, indent=1, allow_nan=False)
-                rel = rel or os.path.relpath(os.path.join(d, "bench_detail.json"), ROOT)
+                rel = rel or os.path.relpath(os.path.join(d, name), ROOT)
             except OSError as e:
                 sys.stderr.write("[bench] could not write the detail record in %s: %s\n" % (d, e))
     line = compact_record(full, rel)
@@ -776,7 +776,11 @@ def main():
             # BASELINE.json configs[0] beside it: the reference's own CPU-runnable case (64x64, B=2, 10 steps)
             out["cpu_baseline"]["config1"] = cpu_baseline(64, batch=2, steps=10, warmup=1)
         sys.stdout.flush()
-        emit(out, json_fd)
+        # the default invocation owns bench_detail.json; any other configuration writes a file of its own name (a profiling run of --gan must
+        # not overwrite the headline's record)
+        tag = "".join(t for t, on in (("_gan", args.gan), ("_bf16", args.bf16), ("_res%d" % args.res, args.res != 256), ("_b%d" % args.batch, args.batch != 32),
+                                      ("_ckpt", args.ckpt_decoder), ("_n%d" % world, world > 1), ("_dist1", args.force_dist and world == 1)) if on)
+        emit(out, json_fd, "bench_detail%s.json" % tag)
     if use_dist:
         dist.destroy_process_group()
 
