@@ -7,8 +7,10 @@ calls the very same library entry points, and `pillow_bilinear_u8` / `pillow_nea
 fixed-point resampler (Resample.c) and nearest mapping (Geometry.c ImagingScaleAffine) in numpy; tests/test_patches.py
 checks the restatement against Pillow itself.  torchvision is absent: ToTensor is restated as u8 -> f32 -> / 255 (its
 documented behaviour; bool masks become 0/1).
-Box arithmetic (which square to cut, which instances to drop): PARITY UNPINNED -- nuscenes.py imports mmdet3d and cannot be
-imported here and the reference has no tests for it; this follows the source statement by statement.
+Box arithmetic (which square to cut, which instances to drop, padding pixels, the mask slice): PINNED since round 5 -- tests/golden/
+make_reference_patch_goldens.py runs the reference's own `NuScenesBase._generate_patch` (nuscenes.py imported unmodified, with stand-ins for the
+absent mmdet3d / pytorch3d / torchvision names; Pillow is the real library) on 40 instances incl. every border and the corner case, and
+tests/test_patches.py holds this file to its outputs bit for bit (tests/test_patches_gpu.py the device path).
 """
 import math
 

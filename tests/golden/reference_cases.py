@@ -65,3 +65,37 @@ def digest_of(t, limit=4096, keep=2048):
 
 def digest(arrays, key, t):
     arrays[key + ".norm"], arrays[key + ".samples"] = digest_of(t)
+
+
+# ---- patch extraction (src/data/datasets/nuscenes.py:90-194 `_generate_patch`) --------------------------------------------------------
+PATCH_S = 96            # network resolution of the fixture (256 in the yaml; the arithmetic is the same, the fixture 7x smaller)
+PATCH_IMAGE_HW = (300, 420)
+
+
+def patch_image():
+    """The synthetic camera image of the patch fixtures: half smooth ramps, half noise, seeded."""
+    h, w = PATCH_IMAGE_HW
+    rng = np.random.default_rng(2024)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx + yy) % 256)], -1).astype(np.uint8)
+    noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    return np.where(rng.random((h, w, 1)) < 0.5, smooth, noise).astype(np.uint8)
+
+
+def patch_instances():
+    """(bbox [x1, y1, x2, y2], center_2d) of the fixtures: ordinary boxes, boxes over every image border, a projected centre outside the image
+    (dropped), a box wholly outside with its centre inside (the reference's corner case, :117-136), wide and tall boxes (padding pixels), an
+    extent of every PATCH_SIZES snap class, fractional coordinates, an empty box."""
+    h, w = PATCH_IMAGE_HW
+    rng = np.random.default_rng(77)
+    out = [([100.2, 80.7, 180.9, 150.1], [140.5, 115.3]), ([-20.5, -10.0, 60.0, 45.5], [19.7, 17.2]), ([380.0, 250.0, 470.0, 330.0], [419.0, 289.6]),
+           ([10.0, 200.0, 130.0, 260.0], [70.0, 230.0]), ([200.0, 20.0, 240.0, 170.0], [220.4, 95.0]), ([150.0, 100.0, 250.0, 200.0], [-3.0, 150.0]),
+           ([150.0, 100.0, 250.0, 200.0], [200.0, 300.0]), ([430.0, 100.0, 500.0, 160.0], [415.0, 130.0]), ([-90.0, 40.0, -10.0, 100.0], [2.0, 70.0]),
+           ([50.0, 50.0, 50.0, 50.0], [50.0, 50.0]), ([5.0, 5.0, 185.0, 150.0], [95.0, 77.5]), ([300.0, 150.0, 420.0, 299.0], [360.0, 224.5]),
+           ([120.9, 130.9, 170.1, 181.1], [145.5, 156.0]), ([0.0, 0.0, 420.0, 300.0], [210.0, 150.0])]
+    for _ in range(26):
+        cx, cy = rng.uniform(-10, w + 10), rng.uniform(-10, h + 10)
+        ex, ey = rng.uniform(4, 170), rng.uniform(4, 170)
+        out.append(([float(cx - ex / 2), float(cy - ey / 2), float(cx + ex / 2), float(cy + ey / 2)],
+                    [float(cx + rng.uniform(-6, 6)), float(cy + rng.uniform(-6, 6))]))
+    return out

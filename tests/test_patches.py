@@ -119,3 +119,68 @@ def test_plan_and_tables_reproduce_the_pil_path(perturb_scale):
         assert np.array_equal(oracle.to_tensor(got), ref[0]), (bbox, center)
         assert np.array_equal(mask.astype(np.float32)[None], ref[4]), (bbox, center)
     assert kept > 20 and dropped > 0
+
+
+# ---- held to the REFERENCE's own code (tests/golden/make_reference_patch_goldens.py ran NuScenesBase._generate_patch unmodified) ----------
+def _ref_gold():
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import reference_cases as rc
+    return np.load(os.path.join(here, "reference_patches.npz")), rc
+
+
+def _crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_oracle_patches_match_the_reference_run(perturb):
+    """Which instances are dropped, the crop (through the resized pixels), the box mask, the crop size, the resampling factor and the padding
+    pixels, for 40 instances incl. every border, the box-outside-image corner case, an empty box and fractional coordinates: BIT-exact
+    (CRC-32 + sum of the u8 patch / mask bytes; four instances carry the bytes themselves)."""
+    g, rc = _ref_gold()
+    img = rc.patch_image()
+    assert int(img.astype(np.int64).sum()) == int(g["image_sum"])
+    S, p = int(g["S"]), int(perturb)
+    kept = []
+    for i, (bbox, center) in enumerate(rc.patch_instances()):
+        out = oracle.generate_patch_pil(img, bbox, center, (S, S), perturb)
+        pre = "p%d.%d" % (p, i)
+        if out[0] is None:
+            assert pre + ".dropped" in g.files, (i, bbox, center)
+            continue
+        kept.append(i)
+        patch, size_sq, factor, pad, mask = out
+        p8, m8 = np.round(patch * 255.0).astype(np.uint8), np.round(mask).astype(np.uint8)
+        assert _crc(p8) == int(g[pre + ".patch_crc"]) and int(p8.astype(np.int64).sum()) == int(g[pre + ".patch_sum"]), i
+        assert _crc(m8) == int(g[pre + ".mask_crc"]) and int(m8.astype(np.int64).sum()) == int(g[pre + ".mask_sum"]), i
+        if pre + ".patch_u8" in g.files:
+            assert np.array_equal(p8, g[pre + ".patch_u8"]) and np.array_equal(m8, g[pre + ".mask_u8"])
+        assert np.array_equal(np.asarray(size_sq, np.float32), g[pre + ".size_sq"])
+        assert tuple(factor) == tuple(g[pre + ".factor"]) and float(pad) == float(g[pre + ".padding_resampled"])
+    assert kept == list(g["p%d.kept" % p]) and len(kept) >= 30
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_product_crop_plans_match_the_reference_run(perturb):
+    """The product's host logic (patches.plan_patch: the integer arithmetic the GPU kernel is driven by) against the same fixture: dropped set,
+    crop size (= the reference's patch.size), padding pixels."""
+    from odvae_amd.patches import plan_patch
+    g, rc = _ref_gold()
+    h, w = rc.PATCH_IMAGE_HW
+    S, p = int(g["S"]), int(perturb)
+    kept = []
+    for i, (bbox, center) in enumerate(rc.patch_instances()):
+        plan = plan_patch(bbox, center, w, h, perturb)
+        pre = "p%d.%d" % (p, i)
+        if plan is None:
+            assert pre + ".dropped" in g.files, i
+            continue
+        kept.append(i)
+        assert np.array_equal(np.asarray([plan.size, plan.size], np.float32), g[pre + ".size_sq"]), i
+        assert float(plan.padding_pixels) * (S / plan.size) == float(g[pre + ".padding_resampled"]), i
+    assert kept == list(g["p%d.kept" % p])

@@ -70,3 +70,42 @@ def test_oversize_crop_and_bad_images_fail_loudly(hip_lib):
         GpuPatcher(patch_height=128)([img.float()], [(0, [100.0, 100.0, 150.0, 140.0], [125.0, 120.0])])
     with pytest.raises(Exception):
         GpuPatcher(patch_height=128)([img.cpu()], [(0, [100.0, 100.0, 150.0, 140.0], [125.0, 120.0])])
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+def test_device_patches_match_the_reference_run(hip_lib, perturb):
+    """csrc/patch_u8.hip through the C ABI against outputs of the REFERENCE's own `NuScenesBase._generate_patch` (tests/golden/
+    reference_patches.npz, written by make_reference_patch_goldens.py): dropped set, crop size, padding pixels, and the u8 patch / mask bytes
+    by CRC-32 + sum -- bit-exact.  Instances whose crop is >= 2 S go through Pillow's box pre-reduction (`reducing_gap=1.0`), which the device
+    path refuses loudly (the 256 / 512 network resolutions never meet it for PATCH_SIZES <= 400); they are checked for exactly that."""
+    import zlib
+    from odvae_amd.patches import GpuPatcher, plan_patch
+    from test_patches import _ref_gold
+    g, rc = _ref_gold()
+    img = rc.patch_image()
+    h, w = rc.PATCH_IMAGE_HW
+    S, p = int(g["S"]), int(perturb)
+    dev_img = torch.from_numpy(img).to("cuda:0")
+    inst, big = [], []
+    for i, (bbox, center) in enumerate(rc.patch_instances()):
+        plan = plan_patch(bbox, center, w, h, perturb)
+        if plan is not None and plan.size >= 2 * S:
+            big.append(i)
+            with pytest.raises(ValueError):
+                GpuPatcher(patch_height=S, perturb_scale=perturb)([dev_img], [(0, bbox, center)])
+            continue
+        inst.append((i, bbox, center))
+    out = GpuPatcher(patch_height=S, perturb_scale=perturb)([dev_img], [(0, b, c) for _, b, c in inst])
+    torch.cuda.synchronize()
+    kept_ref = [i for i in g["p%d.kept" % p] if i not in big]
+    assert [inst[j][0] for j in out.kept] == kept_ref and len(kept_ref) >= 20
+    patch = (out.patch.cpu().numpy() * 255.0).round().astype(np.uint8)
+    mask = out.mask.cpu().numpy().round().astype(np.uint8)
+    for j, i in enumerate(kept_ref):
+        pre = "p%d.%d" % (p, i)
+        assert np.array_equal(patch[j].astype(np.float32) / np.float32(255), out.patch[j].cpu().numpy())      # the f32 values ARE u8 / 255
+        assert zlib.crc32(np.ascontiguousarray(patch[j]).tobytes()) == int(g[pre + ".patch_crc"]), i
+        assert zlib.crc32(np.ascontiguousarray(mask[j]).tobytes()) == int(g[pre + ".mask_crc"]), i
+        assert np.array_equal(out.patch_size[j].numpy(), g[pre + ".size_sq"])
+        assert tuple(out.resampling_factor[j]) == tuple(g[pre + ".factor"])
+        assert float(out.padding_pixels_resampled[j]) == float(g[pre + ".padding_resampled"])
