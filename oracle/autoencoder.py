@@ -3,7 +3,10 @@
 Follows src/models/autoencoder.py (forward :208-257, encode :176-182, pose head :126-174, dropout schedule :184-206,
 training_step :295-330, _rescale :434-436, configure_optimizers :365-377) with the [UPSTREAM] ldm AutoencoderKL.decode
 (post_quant_conv then decoder).  RNG draws are parameters so the HIP path can be fed the same noise.
-PARITY UNPINNED (no reference fixtures exist; the reference cannot be imported here: ModuleNotFoundError ldm).
+PINNED since round 5 against outputs of the reference's OWN src/models/autoencoder.py, imported unmodified in the build container with stand-ins for the
+absent third-party names (tests/golden/make_reference_goldens.py -> reference_glue.npz; tests/test_reference_glue.py: dropout schedule, training_step for both
+optimizer indices, validation_step, and the headline network's step, loss / logs / every parameter gradient).  The Encoder / Decoder underneath (ldm_model.py)
+remain a restatement of absent upstream code: parity unpinned for that layer.
 """
 import numpy as np
 import torch

@@ -1,5 +1,6 @@
 """ORACLE (test infrastructure): src/util/distributions.py:5-41 on top of the [UPSTREAM]
-ldm/modules/distributions/distributions.py DiagonalGaussianDistribution, restated with torch CPU ops."""
+ldm/modules/distributions/distributions.py DiagonalGaussianDistribution, restated with torch CPU ops.  kl() / kl(other) are held to outputs of the
+reference's own file (tests/golden/reference_glue.npz, tests/test_reference_glue.py); the upstream base class members are a restatement."""
 import torch
 
 

@@ -8,7 +8,8 @@ its published algorithm with torch.nn.functional ops, which are the numerical gr
 
 PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path,
 and the reference itself cannot be imported here (ModuleNotFoundError: ldm).  The only piece pinned
-against real reference code is the pose encoder (tests/golden/pose_encoder_ref.npz).
+against real reference code is the pose encoder (tests/golden/pose_encoder_ref.npz); since round 5 the reference's own loss / model / distribution /
+patch code is run on top of THIS file's Encoder / Decoder (tests/golden/make_reference_goldens.py), which pins the glue, not this file.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """

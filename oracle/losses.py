@@ -4,7 +4,10 @@ Follows src/modules/losses/contperceptual.py of the reference line by line in me
 un-vendored pieces it imports: [UPSTREAM] ldm/modules/losses/contperceptual.py (LPIPSWithDiscriminator ctor,
 calculate_adaptive_weight), taming/modules/losses/vqperceptual.py (adopt_weight, hinge_d_loss),
 taming/modules/discriminator/model.py (NLayerDiscriminator, weights_init), taming/modules/losses/lpips.py (LPIPS
-structure) and mmdet FocalLoss defaults.  PARITY UNPINNED: the reference holds no fixtures for any of this.
+structure) and mmdet FocalLoss defaults.  PoseLoss itself (contperceptual.py, which IS in the reference) is PINNED since round 5: the reference's file is
+imported unmodified and run (tests/golden/make_reference_goldens.py) and tests/test_reference_glue.py holds this restatement to its outputs on eight cases x both
+optimizer indices (loss, every logged term, gradients).  The upstream pieces (PatchGAN, LPIPS structure, hinge loss, adaptive weight, focal loss) stay
+restatements of code that is absent here: parity unpinned for those.
 Full-size tensors are materialised exactly as the reference does (rec_loss [B,3,H,W], broadcasts, host branches).
 """
 import math
