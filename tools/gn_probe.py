@@ -1,5 +1,7 @@
 """GroupNorm + swish forward / backward timing on one tensor shape (f32 or bf16); also served the Infinity-Cache sub-batching
-experiment recorded in DESIGN.md 7 (rejected).  usage: python tools/gn_probe.py [f32|bf16] [N C H iters]"""
+experiment recorded in DESIGN.md 7 (rejected).  NOTE: every iteration ends in a device synchronisation, so the BACKWARD figure brackets the host's launch
+gaps of the autograd backward (four launches issued into an empty queue) as well as its kernels -- read per-kernel rates from a kernel trace or the PMC cycle
+counts (profiles/r05_bf16_conv_pmc.txt), not from here.  usage: python tools/gn_probe.py [f32|bf16] [N C H iters]"""
 import os
 import sys
 import torch
